@@ -1,0 +1,204 @@
+/*
+ * sphx.h -- C ABI of libsphx.so, the MI355X (gfx950) HIP implementation of the per-step SPH hot
+ * path of KIYOYOZU/SPH-Poiseuille-Flow.
+ *
+ * Boundary being replaced: the two MEX gateways
+ *     sph_neighbor_search_mex   (reference mex/sph_neighbor_search_mex.c:185, 5 in / 7 out)
+ *     sph_physics_shell_mex     (reference mex/sph_physics_mex.c:1745, mode string + per-mode arity)
+ * called from SPH_Poiseuille.m:167,169,366,380,388,398,406,419,428.
+ *
+ * Conventions (identical to the MEX surface):
+ *   - every array is IEEE double, column-major: [n x 2] = x column then y column, B[n x 4] =
+ *     B11|B12|B21|B22 columns (sph_physics_mex.c:362-365);
+ *   - pair_i / pair_j hold 1-based particle indices stored as doubles
+ *     (sph_neighbor_search_mex.c:375-376); fluid-fluid pairs appear once with i < j, fluid-wall
+ *     pairs once with the fluid particle as i; wall particles are rows n_fluid..n_total-1;
+ *   - inputs are borrowed and never written; outputs are caller-allocated with the sizes the MEX
+ *     gateway would mxCreateDoubleMatrix.
+ * All pointers are HOST pointers unless a name ends in _dev.  Functions return SPHX_OK (0) or a
+ * negative status; sphx_last_error()/sphx_last_error_id() give the message and the MEX-style id
+ * ("SPH:Neighbor:count", "SPH:Physics:int1:B" ...) a gateway passes to mexErrMsgIdAndTxt.
+ * Thread model: like MATLAB, one caller thread per context; the library is not re-entrant on one
+ * context.  There is no CPU fallback: without a HIP device every compute entry point fails with
+ * SPHX_ERR_DEVICE.
+ */
+#ifndef SPHX_H
+#define SPHX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHX_OK 0
+#define SPHX_ERR_ARG (-1)      /* invalid argument (message carries the MEX id)                      */
+#define SPHX_ERR_DEVICE (-2)   /* no HIP device / HIP runtime error                                  */
+#define SPHX_ERR_STATE (-3)    /* call sequence error (e.g. fetch without search)                    */
+#define SPHX_ERR_DIVERGED (-4) /* dt collapsed below 1e-14 (SPH_Poiseuille.m:260-263)                */
+#define SPHX_ERR_GRID (-5)     /* particle left the cell grid / cell displacement bound violated      */
+
+const char *sphx_version(void);
+const char *sphx_last_error(void);
+const char *sphx_last_error_id(void);
+int sphx_device_count(void);
+int sphx_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. Stateless MEX-surface entry points (one per gateway call).  Host arrays in, host arrays out;
+ *    the work runs in HIP kernels on the current device.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* [pair_i,pair_j,dx,dy,r,W,dW] = sph_neighbor_search_mex(pos,n_fluid,n_total,h,DL)
+ * (sph_neighbor_search_mex.c:12-28,185-421).  n_pairs is an output, so the call is two-phase: search
+ * keeps the pair list in library-owned device memory and reports its length; fetch copies it into
+ * caller arrays of at least that length and releases it.  Pairs come out ordered by i, then j. */
+int sphx_neighbor_search(const double *pos, int n_fluid, int n_total, double h, double DL,
+                         size_t *n_pairs);
+int sphx_neighbor_fetch(double *pair_i, double *pair_j, double *dx, double *dy, double *r,
+                        double *W, double *dW, size_t capacity);
+
+/* 'density_correction' (sph_physics_mex.c:95-374): rho[n_total], Vol[n_total], B[n_total x 4]. */
+int sphx_density_correction(size_t n_pairs, const double *pair_i, const double *pair_j,
+                            const double *dx, const double *dy, const double *r, const double *W,
+                            const double *dW, const double *mass, int n_fluid, int n_total,
+                            double rho0, double h, double inv_sigma0, double *rho, double *Vol,
+                            double *B);
+
+/* 'viscous_force' (sph_physics_mex.c:396-550): force[n_total x 2]. */
+int sphx_viscous_force(size_t n_pairs, const double *pair_i, const double *pair_j,
+                       const double *dx, const double *dy, const double *r, const double *dW,
+                       const double *vel, const double *Vol, const double *B, double mu, double h,
+                       int n_fluid, int n_total, const double *mass, const double *wall_vel,
+                       double *force);
+
+/* 'transport_correction' (sph_physics_mex.c:569-714): pos_out[n_total x 2].  The 13-argument MEX
+ * form uses transport_coeff = 0.2 (:584); the gateway passes that default explicitly. */
+int sphx_transport_correction(size_t n_pairs, const double *pair_i, const double *pair_j,
+                              const double *dx, const double *dy, const double *r,
+                              const double *dW, const double *Vol, const double *B,
+                              const double *pos, double h, int n_fluid, int n_total,
+                              double transport_coeff, double *pos_out);
+
+/* 'integration_1st' (sph_physics_mex.c:736-967): rho, p, pos, force, drho(diss). */
+int sphx_integration_1st(size_t n_pairs, const double *pair_i, const double *pair_j,
+                         const double *dx, const double *dy, const double *r, const double *dW,
+                         const double *Vol, const double *B, const double *rho, const double *mass,
+                         const double *pos, const double *vel, const double *drho_dt,
+                         const double *force_prior, double dt, int n_fluid, int n_total,
+                         double rho0, double p0, double c_f, const double *wall_vel,
+                         double *rho_out, double *p_out, double *pos_out, double *force_out,
+                         double *drho_out);
+
+/* 'integration_2nd' (sph_physics_mex.c:987-1119): pos, drho_dt, zeros[n_total x 2] (may be NULL). */
+int sphx_integration_2nd(size_t n_pairs, const double *pair_i, const double *pair_j,
+                         const double *dx, const double *dy, const double *r, const double *dW,
+                         const double *Vol, const double *rho, const double *pos,
+                         const double *vel, double dt, int n_fluid, int n_total,
+                         const double *wall_vel, double *pos_out, double *drho_out,
+                         double *zeros_out);
+
+/* 'integration_verlet' (sph_physics_mex.c:1316-1469): rho, p, pos, vel, drho_dt, force. */
+int sphx_integration_verlet(size_t n_pairs, const double *pair_i, const double *pair_j,
+                            const double *dx, const double *dy, const double *r, const double *dW,
+                            const double *Vol, const double *B, const double *rho,
+                            const double *mass, const double *pos, const double *vel,
+                            const double *drho_dt, const double *force_prior, double dt,
+                            int n_fluid, int n_total, double rho0, double p0, double c_f,
+                            const double *wall_vel, double *rho_out, double *p_out,
+                            double *pos_out, double *vel_out, double *drho_out, double *force_out);
+
+/* 'advance_shell_step' (sph_physics_mex.c:1490-1639): density -> viscous(+mass*g) -> transport(0.2)
+ * -> verlet in one call; 9 outputs rho,p,pos,vel,drho_dt,force,force_prior,Vol,B (:1623-1631). */
+int sphx_advance_shell_step(size_t n_pairs, const double *pair_i, const double *pair_j,
+                            const double *dx, const double *dy, const double *r, const double *W,
+                            const double *dW, const double *mass, const double *pos,
+                            const double *vel, const double *wall_vel, const double *rho,
+                            const double *drho_dt, double dt, int n_fluid, int n_total,
+                            double rho0, double p0, double c_f, double mu, double h,
+                            double inv_sigma0, double gravity_g, double *rho_out, double *p_out,
+                            double *pos_out, double *vel_out, double *drho_out, double *force_out,
+                            double *force_prior_out, double *Vol_out, double *B_out);
+
+/* 'wall_shear_monitor' (sph_physics_mex.c:1653-1743): tau_bottom, tau_top. */
+int sphx_wall_shear_monitor(size_t n_pairs, const double *pair_i, const double *pair_j,
+                            const double *dx, const double *dy, const double *r, const double *dW,
+                            const double *pos, const double *vel, const double *wall_vel,
+                            const double *Vol, const double *B, int n_fluid, int n_total, double DL,
+                            double DH, double mu, double h, double *tau_bottom, double *tau_top);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Device-resident context: the whole step loop of SPH_Poiseuille.m:250-292 stays in HBM.
+ *    One context = one x-slab of the channel on one GPU (slab == whole channel for one GPU).
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct sphx_ctx sphx_ctx;
+
+typedef struct sphx_params {
+    /* physical / numerical constants, SPH_Poiseuille.m:46-80 */
+    double DL, DH, dp, h;
+    double rho0, mu, c_f, p0, inv_sigma0, gravity_g;
+    double transport_coeff; /* 0.30 in the main loop (:77); 0.2 reproduces advance_shell_step        */
+    double t_end;           /* loop bound, SPH_Poiseuille.m:247                                     */
+    int32_t sort_interval;  /* kept for signature parity; the device re-sorts by cell every step     */
+    int32_t lanes_per_particle; /* 0 = auto; 1,2,4,8,16,32: lanes cooperating on one neighbour ring */
+    int32_t steps_per_graph;    /* 0 = auto; steps captured per hipGraph replay (even)               */
+    int32_t reserved;
+} sphx_params;
+
+typedef struct sphx_status {
+    double t;            /* simulated time reached                                                  */
+    double dt_last;      /* dt of the last completed step                                           */
+    double dt_next;      /* dt the next step would use                                              */
+    double vmax;         /* max |v| over fluid after the last step (SPH_Poiseuille.m:286)           */
+    int64_t step;        /* steps completed since creation (state.step)                             */
+    int32_t done;        /* 1 when t >= t_target - 1e-12                                            */
+    int32_t device_status; /* 0 ok, else SPHX_ERR_DIVERGED / SPHX_ERR_GRID raised on device          */
+} sphx_status;
+
+/* Create a context from host state in MEX layout.  pos/vel/wall_vel [n_total x 2]; drho_dt, mass
+ * [n_total].  Rows 0..n_fluid-1 fluid, the rest wall (SPH_Poiseuille.m:107).  Builds the cell grid
+ * (the neighbour structure of SPH_Poiseuille.m:167) on the device. */
+int sphx_ctx_create(sphx_ctx **ctx, const sphx_params *prm, int n_fluid, int n_total,
+                    const double *pos, const double *vel, const double *drho_dt,
+                    const double *mass, const double *wall_vel, double t0, int64_t step0);
+void sphx_ctx_destroy(sphx_ctx *ctx);
+
+/* Run steps until t >= t_target - 1e-12 (one pass of the inner while of SPH_Poiseuille.m:250; dt is
+ * clipped by remain = min(t_target - t, t_end - t), :252) or until max_steps steps have been taken
+ * (max_steps <= 0: unlimited).  Blocks until the device is idle. */
+int sphx_ctx_advance(sphx_ctx *ctx, double t_target, int64_t max_steps, sphx_status *status);
+
+/* Enqueue exactly n_steps steps without host synchronisation (benchmark / pipelined use), dt clipped
+ * only by t_end.  sphx_ctx_sync waits and reports. */
+int sphx_ctx_enqueue_steps(sphx_ctx *ctx, int64_t n_steps);
+int sphx_ctx_sync(sphx_ctx *ctx, sphx_status *status);
+
+/* Copy state back in the caller's original row order.  Any pointer may be NULL.  rho,p,force,
+ * force_prior,Vol,B are those of the last completed step (what integration_verlet / density_correction
+ * returned in SPH_Poiseuille.m:254-266). */
+int sphx_ctx_download(sphx_ctx *ctx, double *pos, double *vel, double *rho, double *p,
+                      double *drho_dt, double *force, double *force_prior, double *Vol, double *B);
+
+/* Monitors of SPH_Poiseuille.m:281-291 on the current neighbour structure: wall shear (new pairs,
+ * new pos/vel, previous Vol/B), pair count of the current list. */
+int sphx_ctx_monitor(sphx_ctx *ctx, double *tau_bottom, double *tau_top, double *n_pairs);
+
+/* The neighbour list the context currently holds, in the MEX convention and the caller's original
+ * row numbering (two-phase like sphx_neighbor_search / sphx_neighbor_fetch). */
+int sphx_ctx_neighbor_list(sphx_ctx *ctx, size_t *n_pairs);
+
+/* Average device time (ms) of each per-step kernel since the last call, measured with HIP events on
+ * the context's stream when profiling is enabled.  names: array of const char* filled by the library. */
+int sphx_ctx_profile_enable(sphx_ctx *ctx, int on);
+int sphx_ctx_profile_read(sphx_ctx *ctx, int capacity, const char **names, double *avg_ms,
+                          int64_t *launches, int *n_kernels);
+
+/* Slab support (multi-GPU x-decomposition).  See DESIGN.md "x-slabs".  */
+int sphx_ctx_info(sphx_ctx *ctx, int *n_fluid, int *n_wall, int *n_cell_x, int *n_cell_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHX_H */

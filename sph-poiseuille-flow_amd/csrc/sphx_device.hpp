@@ -1,0 +1,147 @@
+// sphx_device.hpp -- per-pair and per-particle SPH formulas shared by the pair-list kernels
+// (stateless MEX surface) and the cell-grid gather kernels (resident step).  gfx950 only.
+//
+// Formula sources (reference file:line):
+//   cubic spline W, dW/dr .......... mex/sph_neighbor_search_mex.c:116-133, mex/sph_physics_mex.c:33-38
+//   density from sigma sums ........ mex/sph_physics_mex.c:218-234
+//   KGC pseudo-inverse blend ....... mex/sph_physics_mex.c:321-366
+//   viscous pair term .............. mex/sph_physics_mex.c:489-535
+//   transport pair term / limiter .. mex/sph_physics_mex.c:656-710
+//   Riemann pressure pair term ..... mex/sph_physics_mex.c:884-950, 1121-1129
+//   continuity pair term ........... mex/sph_physics_mex.c:1090-1108
+//   wall shear pair term ........... mex/sph_physics_mex.c:1726-1738
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sphx {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kEpsReg = 1e-8;  // EPS_REG, sph_physics_mex.c:30
+constexpr double kRMin = 1e-12;   // pair filter r <= 1e-12 (sph_physics_mex.c:246,477,...)
+constexpr double kR2Min = 1e-24;  // neighbour filter r^2 > 1e-24 (sph_neighbor_search_mex.c:368)
+
+struct KernelConst {
+    double h, inv_h, sigma, sigma_over_h, rcut2;
+};
+
+__host__ __device__ inline KernelConst make_kernel_const(double h)
+{
+    KernelConst k;
+    k.h = h;
+    k.inv_h = 1.0 / h;
+    k.sigma = 10.0 / (7.0 * kPi * h * h);
+    k.sigma_over_h = k.sigma / h;
+    k.rcut2 = (2.0 * h) * (2.0 * h);
+    return k;
+}
+
+// W and dW/dr for r < 2h (callers have already applied the cut-off).
+__device__ __forceinline__ void spline(const KernelConst &kc, double r, double &W, double &dW)
+{
+    const double q = r * kc.inv_h;
+    if (q < 1.0) {
+        W = kc.sigma * (1.0 - 1.5 * q * q + 0.75 * q * q * q);
+        dW = kc.sigma_over_h * (-3.0 * q + 2.25 * q * q);
+    } else if (q < 2.0) {
+        const double tq = 2.0 - q;
+        W = kc.sigma * 0.25 * tq * tq * tq;
+        dW = -kc.sigma_over_h * 0.75 * tq * tq;
+    } else {
+        W = 0.0;
+        dW = 0.0;
+    }
+}
+
+__device__ __forceinline__ double spline_dW(const KernelConst &kc, double r)
+{
+    const double q = r * kc.inv_h;
+    if (q < 1.0) return kc.sigma_over_h * (-3.0 * q + 2.25 * q * q);
+    if (q < 2.0) { const double tq = 2.0 - q; return -kc.sigma_over_h * 0.75 * tq * tq; }
+    return 0.0;
+}
+
+__device__ __forceinline__ double spline_W(const KernelConst &kc, double r)
+{
+    const double q = r * kc.inv_h;
+    if (q < 1.0) return kc.sigma * (1.0 - 1.5 * q * q + 0.75 * q * q * q);
+    if (q < 2.0) { const double tq = 2.0 - q; return kc.sigma * 0.25 * tq * tq * tq; }
+    return 0.0;
+}
+
+// rho from the two sigma sums; sigma_inner already includes W(0).
+__device__ __forceinline__ double density_from_sigma(double sigma_inner, double sigma_contact,
+                                                     double mass_i, double rho0, double inv_sigma0)
+{
+    double rhoi = sigma_inner * rho0 * inv_sigma0;
+    rhoi += sigma_contact * rho0 * rho0 * inv_sigma0 / mass_i;
+    if (rhoi <= 1e-12) rhoi = rho0;
+    return rhoi;
+}
+
+struct Mat2 {
+    double m11, m12, m21, m22;
+};
+
+// B = w1 * pinv_reg(A) + w2 * I
+__device__ __forceinline__ Mat2 kgc_from_A(double a11, double a12, double a21, double a22)
+{
+    const double ata11 = a11 * a11 + a21 * a21 + kEpsReg;
+    const double ata12 = a11 * a12 + a21 * a22;
+    const double ata22 = a12 * a12 + a22 * a22 + kEpsReg;
+    const double det_m = ata11 * ata22 - ata12 * ata12;
+    double p11, p12, p21, p22;
+    if (fabs(det_m) < 1e-20) {
+        p11 = 1.0; p12 = 0.0; p21 = 0.0; p22 = 1.0;
+    } else {
+        const double im11 = ata22 / det_m, im12 = -ata12 / det_m, im22 = ata11 / det_m;
+        p11 = im11 * a11 + im12 * a12;
+        p12 = im11 * a21 + im12 * a22;
+        p21 = im12 * a11 + im22 * a12;
+        p22 = im12 * a21 + im22 * a22;
+    }
+    const double det_a = a11 * a22 - a12 * a21;
+    const double det_sqr = fmax(1.0 - det_a, 0.0);
+    const double denom = det_a + det_sqr;
+    double w1, w2;
+    if (fabs(denom) < 1e-12) { w1 = 0.0; w2 = 1.0; }
+    else { w1 = det_a / denom; w2 = det_sqr / denom; }
+    Mat2 B;
+    B.m11 = w1 * p11 + w2;
+    B.m12 = w1 * p12;
+    B.m21 = w1 * p21;
+    B.m22 = w1 * p22 + w2;
+    return B;
+}
+
+__device__ __forceinline__ double riemann_beta(double un_l, double un_r, double c_f)
+{
+    double compression = un_l - un_r;
+    if (compression < 0.0) compression = 0.0;
+    return fmin(3.0 * compression, c_f);
+}
+
+// transport limiter: pos += coeff*h^2 * clamp(100|inc|^2/h^2,0,1) * inc
+__device__ __forceinline__ void transport_shift(double inc_x, double inc_y, double h, double coeff,
+                                                double &sx, double &sy)
+{
+    const double n2 = inc_x * inc_x + inc_y * inc_y;
+    double limiter = 100.0 * n2 / (h * h);
+    const double scale = coeff * h * h;
+    if (limiter > 1.0) limiter = 1.0;
+    if (limiter < 0.0) limiter = 0.0;
+    sx = scale * limiter * inc_x;
+    sy = scale * limiter * inc_y;
+}
+
+__device__ __forceinline__ double eos_pressure(double rho, double rho0, double p0)
+{
+    return p0 * (rho / rho0 - 1.0);
+}
+
+// order-preserving bits of a non-negative double, for atomicMax
+__device__ __forceinline__ unsigned long long nonneg_bits(double v)
+{
+    return (unsigned long long)__double_as_longlong(v);
+}
+
+}  // namespace sphx
