@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the device-resident SPH step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload C2|C3|C4|C5|dp=..,DL=..]
+
+A "step" is one full time step of SPH_Poiseuille.m:250-292 (density/KGC, viscous+gravity, transport
+shift, dt rule, Verlet integration, periodic wrap, neighbour rebuild) on synthetic particles that are
+resident in HBM when the timed region starts.  N=1 runs BASELINE.json's headline configuration
+(configs[1]: dp = 0.025, DL = 3, DH = 1 -> 5 760 particles); N>1 shards the channel into x-slabs, one
+rank per GPU.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+PKG = "sph-poiseuille-flow_amd"
+
+WORKLOADS = {  # BASELINE.json configs; actual particle counts are those of the reference initialiser
+    "C1": dict(dp=0.04, DL=3.0),
+    "C2": dict(dp=0.025, DL=3.0),
+    "C3": dict(dp=0.01, DL=6.0),
+    "C4": dict(dp=0.005, DL=12.0),
+    "C5": dict(dp=0.002, DL=24.0),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic bytes per fluid particle per pass mapped onto our kernels
+BYTES_PER_FLUID = {"k_density": 40, "k_kgc": 56, "k_forces": 112 + 192, "k_continuity": 104,
+                   "k_clock_scan": 0, "k_scatter": 8, "k_reorder": 16}
+BYTES_PER_WALL = {"k_density": 24, "k_kgc": 24, "k_forces": 48, "k_continuity": 24}
+STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
+
+
+def parse_workload(s):
+    if s in WORKLOADS:
+        return s, dict(WORKLOADS[s])
+    kw = {}
+    for part in s.split(","):
+        k, v = part.split("=")
+        kw[k.strip()] = float(v)
+    return s, kw
+
+
+def cpu_baseline(cfg, geo, prm, parts, budget_s=20.0):
+    """Oracle (kind 'port': our C restatement of the reference MEX path, same serial neighbour search +
+    OpenMP parallel-for/atomic pair loops) on this box's host cores, bounded sample of the same workload."""
+    import oracle
+    oracle.build()
+    threads = oracle.num_threads(omp=True)
+    nt = parts["n_total"]
+    # calibrate with a few steps, then size the sample to ~budget_s
+    t0 = time.perf_counter()
+    oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=5, enable_sort=False, omp=True)
+    per_step = max((time.perf_counter() - t0) / 5, 1e-6)
+    n = int(max(10, min(20000, budget_s / per_step)))
+    t0 = time.perf_counter()
+    st = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=n, enable_sort=True, omp=True)
+    dt = time.perf_counter() - t0
+    return dict(value=nt * st["stats"]["steps"] / dt, unit="particle-steps/s", cores=int(threads), kind="port",
+                sample=f"{st['stats']['steps']} steps of the same {nt}-particle workload "
+                       f"({st['stats']['seconds_neighbor']:.1f}s serial neighbour search + "
+                       f"{st['stats']['seconds_physics']:.1f}s OpenMP pair loops, {threads} threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--workload", default=None, help="C1..C5 or 'dp=0.01,DL=6' (default: C2 at 1 GPU)")
+    ap.add_argument("--lpp", type=int, default=0, help="lanes per particle (0 = auto)")
+    ap.add_argument("--spg", type=int, default=0, help="steps per hipGraph replay (0 = auto)")
+    ap.add_argument("--profile-steps", type=int, default=200, help="eager steps timed per kernel with HIP events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--lattice", action="store_true", help="pristine lattice start instead of the developed state")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (libsphx has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    pkg = importlib.import_module(PKG)
+    cfg, geo, capi = pkg.config, pkg.geometry, pkg.capi
+    capi.set_device(local_rank)
+
+    if world > 1:
+        slab = importlib.import_module(PKG + ".slab")
+        return slab.bench_main(args, rank, world, local_rank)
+
+    name, kw = parse_workload(args.workload or "C2")
+    prm = cfg.params_from_values(end_time=1e9, **kw)
+    parts = geo.init_particles(prm)
+    nf, nw, nt = parts["n_fluid"], parts["n_wall"], parts["n_total"]
+    if args.lattice:
+        pos, vel, start = parts["pos"], parts["vel"], "lattice at rest"
+    else:
+        pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
+        start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
+
+    ctx = capi.Context(prm, nf, nt, pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9,
+                       lanes_per_particle=args.lpp, steps_per_graph=args.spg)
+    info = ctx.info()
+    tuning = ctx.tuning()
+    # warm-up (untimed): includes graph capture/instantiation
+    if args.warmup > 0:
+        ctx.enqueue_steps(args.warmup)
+    st0 = ctx.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.enqueue_steps(args.steps)
+    st1 = ctx.sync()
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    assert st1["step"] - st0["step"] == args.steps, (st0, st1)
+    value = nt * args.steps / seconds
+
+    # per-kernel device time, live, with HIP events on the context's stream (eager launches)
+    roof = None
+    kernels = {}
+    if args.profile_steps > 0:
+        ctx.profile_enable(True)
+        ctx.advance(1e9, max_steps=args.profile_steps)
+        kernels = ctx.profile_read()
+        ctx.profile_enable(False)
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+            ms = kernels[dom]["avg_ms"]
+            alg = BYTES_PER_FLUID.get(dom, 0) * nf + BYTES_PER_WALL.get(dom, 0) * nw
+            achieved = alg / (ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, launch_ms=ms, algorithmic_bytes=alg,
+                        step_achieved=(STEP_BYTES_FLUID * nf + STEP_BYTES_WALL * nw) * args.steps / seconds / 1e9)
+    ctx.close()
+
+    out = {
+        "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * seconds / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{name}: dp={prm.dp}, DL={prm.DL}, DH={prm.DH}, n_fluid={nf}, n_wall={nw}, "
+                               f"n_total={nt}, c_f={prm.c_f}, transport_coeff={prm.transport_coeff}; start={start}",
+                   "cells": [info["n_cell_x"], info["n_cell_y"]], "lanes_per_particle": tuning["lanes_per_particle"], "steps_per_graph": tuning["steps_per_graph"],
+                   "parallelism": "1 GPU, device-resident loop, hipGraph replay"},
+        "roofline": roof,
+        "kernels_ms": {k: round(v["avg_ms"], 6) for k, v in kernels.items()},
+        "sim": {"t": st1["t"], "dt": st1["dt_last"], "vmax": st1["vmax"]},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, geo, prm, dict(parts, pos=pos, vel=vel), args.cpu_budget)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

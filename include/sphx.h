@@ -195,6 +195,9 @@ int sphx_ctx_profile_enable(sphx_ctx *ctx, int on);
 int sphx_ctx_profile_read(sphx_ctx *ctx, int capacity, const char **names, double *avg_ms,
                           int64_t *launches, int *n_kernels);
 
+/* The launch shape the context chose (lanes cooperating per particle, steps per hipGraph replay). */
+int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph);
+
 /* Slab support (multi-GPU x-decomposition).  See DESIGN.md "x-slabs".  */
 int sphx_ctx_info(sphx_ctx *ctx, int *n_fluid, int *n_wall, int *n_cell_x, int *n_cell_y);
 

@@ -48,7 +48,7 @@ EXPORTS = [
     "sphx_integration_verlet", "sphx_advance_shell_step", "sphx_wall_shear_monitor",
     "sphx_ctx_create", "sphx_ctx_destroy", "sphx_ctx_advance", "sphx_ctx_enqueue_steps", "sphx_ctx_sync",
     "sphx_ctx_download", "sphx_ctx_monitor", "sphx_ctx_neighbor_list", "sphx_ctx_profile_enable",
-    "sphx_ctx_profile_read", "sphx_ctx_info",
+    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning",
 ]
 
 _LIB = None
@@ -170,6 +170,11 @@ class Context:
         a, b, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().sphx_ctx_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(n_fluid=a.value, n_wall=b.value, n_cell_x=c.value, n_cell_y=d.value)
+
+    def tuning(self):
+        a, b = C.c_int(0), C.c_int(0)
+        check(lib().sphx_ctx_tuning(self._h, C.byref(a), C.byref(b)))
+        return dict(lanes_per_particle=a.value, steps_per_graph=b.value)
 
     def profile_enable(self, on=True):
         check(lib().sphx_ctx_profile_enable(self._h, C.c_int(1 if on else 0)))

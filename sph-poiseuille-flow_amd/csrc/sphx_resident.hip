@@ -1433,3 +1433,13 @@ SPHX_EXPORT int sphx_ctx_info(sphx_ctx *c, int *n_fluid, int *n_wall, int *n_cel
     return SPHX_OK;
     SPHX_CATCH
 }
+
+SPHX_EXPORT int sphx_ctx_tuning(sphx_ctx *c, int *lanes_per_particle, int *steps_per_graph)
+{
+    SPHX_TRY
+    require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    if (lanes_per_particle) *lanes_per_particle = c->lpp;
+    if (steps_per_graph) *steps_per_graph = c->spg;
+    return SPHX_OK;
+    SPHX_CATCH
+}

@@ -8,7 +8,7 @@ membership, 1e-14 relative on dx,dy,r and 1e-12 on W,dW.
 import numpy as np
 import pytest
 
-from helpers import assert_close, canon_pairs, make_case
+from helpers import assert_close, canon_pairs, field_atol, make_case
 
 pytestmark = pytest.mark.gpu
 
@@ -67,7 +67,7 @@ def test_viscous_force(case, mex, oracle):
     ref = oracle.viscous_force(nb, parts["vel"], Vol, B, prm.mu, prm.h, nf, nt, parts["mass"], parts["wall_vel"])
     got = mex.sph_physics_shell_mex("viscous_force", *p6, parts["vel"], Vol, B, prm.mu, prm.h, nf, nt, parts["mass"],
                                     parts["wall_vel"])
-    assert_close(got, ref, rtol=1e-10, atol_scale=1e-12, name="force")
+    assert_close(got, ref, rtol=1e-10, atol=field_atol(prm, parts, nb, 0.0)["force"], name="force")
 
 
 def test_transport_correction(case, mex, oracle):
@@ -95,20 +95,21 @@ def test_integration_1st_2nd_verlet(case, mex, oracle):
               prm.p0, prm.c_f, parts["wall_vel"])
     ref1 = oracle.integration_1st(nb, *common)
     got1 = mex.sph_physics_shell_mex("integration_1st", *p6, *common)
+    at = field_atol(prm, parts, nb, dt)
     for g, r, name in zip(got1, ref1, ("rho", "p", "pos", "force", "drho")):
-        assert_close(g, r, rtol=1e-10, atol_scale=1e-12, name="int1." + name)
+        assert_close(g, r, rtol=1e-10, atol=at[name], name="int1." + name)
     rho_h, p_h, pos_h, force1, _ = ref1
     vel_new = parts["vel"].copy(order="F")
     vel_new[:nf] += (fp[:nf] + force1[:nf]) / parts["mass"][:nf, None] * dt
     ref2 = oracle.integration_2nd(nb, Vol, rho_h, pos_h, vel_new, dt, nf, nt, parts["wall_vel"])
     got2 = mex.sph_physics_shell_mex("integration_2nd", *p6, Vol, rho_h, pos_h, vel_new, dt, nf, nt, parts["wall_vel"])
     for g, r, name in zip(got2, ref2, ("pos", "drho", "zeros")):
-        assert_close(g, r, rtol=1e-10, atol_scale=1e-12, name="int2." + name)
+        assert_close(g, r, rtol=1e-10, atol=at[name], name="int2." + name)
     assert not np.any(got2[2])
     refv = oracle.integration_verlet(nb, *common)
     gotv = mex.sph_physics_shell_mex("integration_verlet", *p6, *common)
     for g, r, name in zip(gotv, refv, ("rho", "p", "pos", "vel", "drho", "force")):
-        assert_close(g, r, rtol=1e-10, atol_scale=1e-12, name="verlet." + name)
+        assert_close(g, r, rtol=1e-10, atol=at[name], name="verlet." + name)
 
 
 def test_advance_shell_step(case, mex, oracle):
@@ -119,8 +120,9 @@ def test_advance_shell_step(case, mex, oracle):
     ref = oracle.advance_shell_step(nb, *tail)
     got = mex.sph_physics_shell_mex("advance_shell_step", *nb, *tail)
     names = ("rho", "p", "pos", "vel", "drho", "force", "force_prior", "Vol", "B")
+    at = field_atol(prm, parts, nb, dt)
     for g, r, name in zip(got, ref, names):
-        assert_close(g, r, rtol=1e-10, atol_scale=1e-12, name="advance." + name)
+        assert_close(g, r, rtol=1e-10, atol=at[name], name="advance." + name)
 
 
 def test_wall_shear_monitor(case, mex, oracle):
