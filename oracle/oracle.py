@@ -240,5 +240,9 @@ def run(prm, parts, t_end=None, output_interval=None, max_steps=0, enable_sort=T
     return st
 
 
+def set_num_threads(n: int, omp=True) -> None:
+    lib(omp).orc_set_num_threads(C.c_int(int(n)))
+
+
 def num_threads(omp=True) -> int:
     return lib(omp).orc_num_threads()

@@ -925,6 +925,16 @@ ORC_API void orc_binned_profile_mean(const double *y_values, const double *u_val
     free(edges);
 }
 
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -101,4 +101,4 @@ def test_ctx_neighbor_list_matches_oracle(case, capi, oracle):
     ref = oracle.neighbor_search(pos, parts["n_fluid"], parts["n_total"], prm.h, prm.DL)
     a, b = canon_pairs(nb), canon_pairs(ref)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    assert_close(a[4], b[4], rtol=1e-13, atol_scale=1e-14, name="r")
+    assert_close(a[4], b[4], rtol=1e-13, atol=1e-15 * prm.DL, name="r")
