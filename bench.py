@@ -144,7 +144,8 @@ def main():
     kernels = {}
     if args.profile_steps > 0:
         ctx.profile_enable(True)
-        ctx.advance(1e9, max_steps=args.profile_steps)
+        ctx.enqueue_steps(args.profile_steps)  # exact slot count: replays of the event-instrumented graph
+        ctx.sync()
         kernels = ctx.profile_read()
         ctx.profile_enable(False)
         if kernels:

@@ -198,8 +198,44 @@ int sphx_ctx_profile_read(sphx_ctx *ctx, int capacity, const char **names, doubl
 /* The launch shape the context chose (lanes cooperating per particle, steps per hipGraph replay). */
 int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph);
 
-/* Slab support (multi-GPU x-decomposition).  See DESIGN.md "x-slabs".  */
-int sphx_ctx_info(sphx_ctx *ctx, int *n_fluid, int *n_wall, int *n_cell_x, int *n_cell_y);
+/* ------------------------------------------------------------------------------------------------
+ * 3. x-slab contexts (multi-GPU).  The channel is cut into n_ranks slabs of whole cell columns; each
+ *    rank (one process per GPU) holds its columns plus halo_cols columns of copies on either side.
+ *    The reference has no counterpart (single process).  One step is
+ *        sphx_slab_compute -> {exchange two messages with the ring neighbours, all-reduce max|v|}
+ *        -> sphx_slab_finish
+ *    All *_dev pointers are DEVICE pointers (e.g. torch tensors) and every call is asynchronous on the
+ *    context's stream (hip_stream of sphx_slab_create, or an internal one when NULL).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Create rank `rank` of `n_ranks` from the GLOBAL host state (same arguments as sphx_ctx_create on
+ * every rank).  halo_cols >= 4. */
+int sphx_slab_create(sphx_ctx **ctx, const sphx_params *prm, int n_fluid, int n_total,
+                     const double *pos, const double *vel, const double *drho_dt, const double *mass,
+                     const double *wall_vel, double t0, int64_t step0, int rank, int n_ranks,
+                     int halo_cols, void *hip_stream);
+/* Message length in doubles (1 + 7*capacity: count, then x,y,vx,vy,drho,mass,id blocks), the owned
+ * global cell columns [col0,col1), current local particle count and array capacity. */
+int sphx_slab_layout(sphx_ctx *ctx, int64_t *msg_doubles, int *col0, int *col1, int *n_local,
+                     int *capacity);
+/* max |v| over the owned particles of the current state -> vmax_dev[0]. */
+int sphx_slab_local_vmax(sphx_ctx *ctx, double *vmax_dev);
+/* Arm the device clock for a run to t_target / at most max_steps (<=0: unlimited) steps; the first dt
+ * uses vmax_global_dev[0] (the all-reduced value). */
+int sphx_slab_prepare(sphx_ctx *ctx, double t_target, int64_t max_steps, const double *vmax_global_dev);
+/* First half of a step: the four neighbour passes, local max |v| -> vmax_local_dev[0], and the two
+ * outgoing messages (left / right ring neighbour). */
+int sphx_slab_compute(sphx_ctx *ctx, double *send_left_dev, double *send_right_dev,
+                      double *vmax_local_dev);
+/* Second half: take the messages received from the left / right neighbour and the global max |v|,
+ * update the clock and rebuild the cell grid. */
+int sphx_slab_finish(sphx_ctx *ctx, const double *recv_left_dev, const double *recv_right_dev,
+                     const double *vmax_global_dev);
+/* Wait for the stream; fails if a step was enqueued after the loop had stopped or a buffer overflowed. */
+int sphx_slab_sync(sphx_ctx *ctx, sphx_status *status);
+/* Host copy of the slab's current particles (owned + halo copies); owned[i] = 1 for owned ones. */
+int sphx_slab_snapshot(sphx_ctx *ctx, int capacity, int *n, double *x, double *y, double *vx,
+                       double *vy, double *drho, int *id, int *owned);
 
 #ifdef __cplusplus
 }

@@ -11,8 +11,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["sphx_common.hip", "sphx_pairlist.hip", "sphx_resident.hip", "sphx_slab.hip"]
-HEADERS = ["sphx_common.hpp", "sphx_device.hpp", os.path.join("..", "..", "include", "sphx.h")]
+SOURCES = ["sphx_common.hip", "sphx_pairlist.hip", "sphx_resident.hip"]
+HEADERS = ["sphx_common.hpp", "sphx_device.hpp", "sphx_kernels.hpp", os.path.join("..", "..", "include", "sphx.h")]
 LIB = os.path.join(CSRC, "libsphx.so")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

@@ -49,6 +49,8 @@ EXPORTS = [
     "sphx_ctx_create", "sphx_ctx_destroy", "sphx_ctx_advance", "sphx_ctx_enqueue_steps", "sphx_ctx_sync",
     "sphx_ctx_download", "sphx_ctx_monitor", "sphx_ctx_neighbor_list", "sphx_ctx_profile_enable",
     "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning",
+    "sphx_slab_create", "sphx_slab_layout", "sphx_slab_local_vmax", "sphx_slab_prepare", "sphx_slab_compute",
+    "sphx_slab_finish", "sphx_slab_sync", "sphx_slab_snapshot",
 ]
 
 _LIB = None

@@ -1,0 +1,963 @@
+// sphx_kernels.hpp -- the device-resident SPH step for MI355X (gfx950): HIP kernels.
+//
+// One time step of SPH_Poiseuille.m:250-292 (density_correction -> viscous_force + gravity ->
+// transport_correction -> verlet_time_step -> integration_verlet -> periodic wrap -> neighbour
+// rebuild) is the kernel chain
+//     k_density -> k_kgc -> k_forces -> k_continuity -> [scan] -> k_scatter -> k_reorder
+// with no host round trip.  Design (long form in DESIGN.md):
+//   * particles live in SoA double arrays sorted by cell, cell id = cx*ncy + cy (y fastest): the 3x3
+//     neighbourhood of a cell is three contiguous index ranges and an x-slab of the channel is one
+//     contiguous range;
+//   * in x the cells tile the period exactly (ncx = floor(DL/2h), width DL/ncx >= 2h), so the wrapped
+//     3x3 sweep with a min-image dx sees every neighbour and the reference's ghost entries +
+//     seen_neighbor (mex/sph_neighbor_search_mex.c:282-295,342,383) are not needed; the accepted set is
+//     the same {1e-24 < r^2 < (2h)^2} (:368).  A slab of a multi-GPU run uses the same kernels on an
+//     open (non-periodic) window of columns;
+//   * k_density sweeps the candidate cells once per step and records the accepted fluid neighbours in
+//     a lane-major index list; the other three passes walk that list (all lanes busy, no cut-off
+//     branch) -- the geometry is frozen for the step exactly as in the reference, which reuses
+//     dx,dy,r,W,dW of the pair list built at the end of the previous step;
+//   * every pair sum is a per-particle gather (each fluid-fluid update of mex/sph_physics_mex.c is
+//     symmetric under i<->j): no atomics in the physics, bitwise reproducible run to run;
+//   * LPP lanes of a wavefront share one particle's ring and combine with __shfl_xor (wave64);
+//   * dt, t, the step counter, the particle count and the stop test live in a device-side clock so
+//     steps can be captured into a hipGraph and replayed.
+#pragma once
+#include "sphx_device.hpp"
+
+namespace sphx {
+
+constexpr int kBlock = 256;
+constexpr int kScanBlock = 1024;
+constexpr int kBigScanCells = 8192;  // above this the cell scan runs as three multi-block kernels
+
+struct Grid {
+    int ncx, ncy, ncells;
+    int periodic;         // 1: columns wrap in x (single GPU); 0: open window (slab)
+    double DL, half_DL;   // min-image: |dx| > half_DL -> dx -+ DL ; half_DL = +inf in an open window
+    double x0, y0, inv_csx, inv_csy;
+    double own_lo, own_hi;  // particles with own_lo <= x < own_hi are owned by this context
+};
+
+struct Phys {
+    KernelConst kc;
+    double rho0, inv_sigma0, mu, p0, c_f, g, tc, nu, DL, DH, w0;
+};
+
+// Device-side clock: replaces the host variables state.t / state.step / dt_step / remain of
+// SPH_Poiseuille.m:247-267 so the loop needs no host decisions.
+struct Clock {
+    double t, dt, dt_last, t_target, t_end, vmax;
+    long long step, steps_left;  // steps_left < 0: unlimited
+    int run[2];                  // run[q]: the step slot of parity q executes
+    int status;
+    int n;                       // particles currently held (fluid, incl. slab halo copies)
+};
+
+struct FluidSet {  // persistent per-particle state, sorted by cell
+    double *x, *y, *vx, *vy, *drho, *mass;
+    int *id;
+    int *start;  // [ncells+1] cell ranges of this ordering
+};
+
+struct FluidTmp {
+    double *xn, *yn, *vxn, *vyn, *drhon;                   // end-of-step state, pre-sort order
+    double *rho, *Vol, *rhoh, *ph, *b11, *b12, *b21, *b22;  // per-step fields
+    double *fpx, *fpy, *fx, *fy, *rho_out, *p_out;         // outputs of the step
+    int *cellid, *count, *perm, *src_of;
+    double *vpart;   // per-block max |v|^2 of pass E (owned particles only)
+    int *nl_idx;     // neighbour list, entry m of lane l at nl_idx[m*nl_stride + l]
+    int *nl_cnt;     // [nl_stride] entries per lane
+    int *flags;      // [1] sticky device status bits (list overflow ...)
+    int *tile_sum;   // big scan: per-tile sums / offsets
+    int nl_stride, nl_cap;
+};
+
+struct Walls {
+    const double *x, *y, *Vol, *vx, *vy;
+    const int *id;
+    const int *start;    // [ncells+1]
+    const int *row_any;  // [ncy] 1 when rows cy-1..cy+1 hold any wall particle
+    int n;
+};
+
+__device__ __forceinline__ void cell_of(const Grid &g, double x, double y, int &cx, int &cy)
+{
+    cx = (int)floor((x - g.x0) * g.inv_csx);
+    cx = min(max(cx, 0), g.ncx - 1);
+    cy = (int)floor((y - g.y0) * g.inv_csy);
+    cy = min(max(cy, 0), g.ncy - 1);
+}
+
+__device__ __forceinline__ double wrap_x(double x, double DL) { return x - floor(x / DL) * DL; }
+
+// minimum-image separation (mex/sph_neighbor_search_mex.c:357-363); a no-op in an open window
+__device__ __forceinline__ double min_image(const Grid &g, double dx)
+{
+    if (dx > g.half_DL) dx -= g.DL;
+    else if (dx < -g.half_DL) dx += g.DL;
+    return dx;
+}
+
+template <int LPP>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int off = LPP / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Visit the candidates of the three cell columns around (cx,cy): body(k).
+template <int LPP, typename Body>
+__device__ __forceinline__ void sweep(const Grid &g, const int *__restrict__ start, int cx, int cy,
+                                      int sub, Body &&body)
+{
+    const int cylo = max(cy - 1, 0), cyhi = min(cy + 1, g.ncy - 1);
+#pragma unroll
+    for (int ox = -1; ox <= 1; ++ox) {
+        int col = cx + ox;
+        if (g.periodic) {
+            if (col < 0) col += g.ncx;
+            else if (col >= g.ncx) col -= g.ncx;
+        } else if (col < 0 || col >= g.ncx) {
+            continue;
+        }
+        const int base = col * g.ncy;
+        const int lo = start[base + cylo], hi = start[base + cyhi + 1];
+        for (int k = lo + sub; k < hi; k += LPP) body(k);
+    }
+}
+
+__device__ __forceinline__ double next_dt(const Clock &c, const Phys &ph)
+{  // SPH_Poiseuille.m:519-527 with remain of :252
+    const double remain = fmin(c.t_target - c.t, c.t_end - c.t);
+    const double h = ph.kc.h;
+    const double dt_acoustic = 0.25 * h / fmax(ph.c_f + c.vmax, 1e-12);
+    const double dt_viscous = 0.125 * h * h / fmax(ph.nu, 1e-12);
+    const double dt_body = 0.25 * sqrt(h / fmax(fabs(ph.g), 1e-12));
+    const double dt = fmin(fmin(dt_acoustic, dt_viscous), fmin(dt_body, remain));
+    return fmax(dt, 1e-12);
+}
+
+__device__ __forceinline__ bool loop_continues(const Clock &c)
+{  // while state.t < target_time - 1e-12 (SPH_Poiseuille.m:250) and step budget left
+    return (c.t < c.t_target - 1e-12) && (c.steps_left != 0) && (c.status == 0);
+}
+
+// one thread: arm the clock for an advance call.  vmax_in (optional) overrides the stored vmax (slab:
+// the all-reduced global value).
+__global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_steps, int q0,
+                          const double *vmax_in)
+{
+    Clock c = *clk;
+    if (vmax_in) c.vmax = *vmax_in;
+    c.t_target = fmin(t_target, c.t_end);  // target_time = min(t + output_interval, t_end), SPH_Poiseuille.m:248
+    c.steps_left = max_steps > 0 ? max_steps : -1;
+    if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
+    c.dt = next_dt(c, ph);
+    const int go = loop_continues(c) ? 1 : 0;
+    c.run[q0] = go;
+    c.run[1 - q0] = 0;
+    *clk = c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass A: candidate sweep -> neighbour list; number-density summation -> rho, Vol
+// (mex/sph_physics_mex.c:188-234) and the half-step density/pressure of integration_1st's pre-pass
+// (:857-862), which only needs own-particle data.
+// ---------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Grid g, Phys ph,
+                                                    FluidSet s, FluidTmp t, Walls w)
+{
+    if (!clk->run[q]) return;
+    const int n = clk->n;
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    const int i = tid / LPP, sub = tid % LPP;
+    const bool active = i < n;
+    double s_in = 0.0, s_ct = 0.0;
+    int cnt = 0;
+    if (active) {
+        const double xi = s.x[i], yi = s.y[i];
+        int cx, cy;
+        cell_of(g, xi, yi, cx, cy);
+        sweep<LPP>(g, s.start, cx, cy, sub, [&](int k) {
+            const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+            const double r2 = dx * dx + dy * dy;
+            if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                s_in += spline_W(ph.kc, sqrt(r2));
+                if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = k;
+                ++cnt;
+            }
+        });
+        if (w.row_any[cy]) {
+            sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
+                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double r2 = dx * dx + dy * dy;
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, sqrt(r2)) * w.Vol[k];
+            });
+        }
+        if (cnt > t.nl_cap) { atomicOr(t.flags, 1); cnt = t.nl_cap; }
+    }
+    if (tid < t.nl_stride) t.nl_cnt[tid] = cnt;
+    s_in = group_sum<LPP>(s_in);
+    s_ct = group_sum<LPP>(s_ct);
+    if (active && sub == 0) {
+        const double m = s.mass[i];
+        const double rho = density_from_sigma(ph.w0 + s_in, s_ct, m, ph.rho0, ph.inv_sigma0);
+        const double dt = clk->dt;
+        double rhoh = rho + 0.5 * dt * s.drho[i];
+        if (rhoh < 1e-10) rhoh = ph.rho0;
+        t.rho[i] = rho;
+        t.Vol[i] = m / rho;
+        t.rhoh[i] = rhoh;
+        t.ph[i] = eos_pressure(rhoh, ph.rho0, ph.p0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass B: kernel-gradient-correction matrix A -> blended pseudo-inverse B
+// (mex/sph_physics_mex.c:239-366)
+// ---------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+                                                FluidTmp t, Walls w)
+{
+    if (!clk->run[q]) return;
+    const int n = clk->n;
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    const int i = tid / LPP, sub = tid % LPP;
+    const bool active = i < n;
+    double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
+    if (active) {
+        const double xi = s.x[i], yi = s.y[i];
+        auto term = [&](double dx, double dy, double Volj) {
+            const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+            const double ex = dx * inv_r, ey = dy * inv_r;
+            const double fxj = spline_dW(ph.kc, r) * Volj;
+            a11 -= dx * (fxj * ex);
+            a12 -= dx * (fxj * ey);
+            a21 -= dy * (fxj * ex);
+            a22 -= dy * (fxj * ey);
+        };
+        const int nn = t.nl_cnt[tid];
+        for (int m = 0; m < nn; ++m) {
+            const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            term(min_image(g, xi - s.x[k]), yi - s.y[k], t.Vol[k]);
+        }
+        int cx, cy;
+        cell_of(g, xi, yi, cx, cy);
+        if (w.row_any[cy]) {
+            sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
+                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double r2 = dx * dx + dy * dy;
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) term(dx, dy, w.Vol[k]);
+            });
+        }
+    }
+    a11 = group_sum<LPP>(a11);
+    a12 = group_sum<LPP>(a12);
+    a21 = group_sum<LPP>(a21);
+    a22 = group_sum<LPP>(a22);
+    if (active && sub == 0) {
+        const Mat2 B = kgc_from_A(a11, a12, a21, a22);
+        t.b11[i] = B.m11;
+        t.b12[i] = B.m12;
+        t.b21[i] = B.m21;
+        t.b22[i] = B.m22;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass CD: viscous force (+gravity) [sph_physics_mex.c:469-545, SPH_Poiseuille.m:392], transport
+// shift [:636-710], Riemann pressure force of integration_1st [:870-957], velocity kick
+// [:1400-1408] and both position half-drifts [:863-864,:1066-1069] + periodic wrap
+// [SPH_Poiseuille.m:570-577].  One walk over the fluid ring serves all three operators because they
+// share e, dW, B_i+B_j; the wall ring is swept twice because the wall pressure needs the complete
+// viscous+gravity force of the particle first (p_wall uses force_prior_i, :931-934).
+// ---------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+                                                   FluidTmp t, Walls w)
+{
+    if (!clk->run[q]) return;
+    const int n = clk->n;
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    const int i = tid / LPP, sub = tid % LPP;
+    const bool active = i < n;
+    const double h = ph.kc.h;
+    double ax = 0.0, ay = 0.0, ix = 0.0, iy = 0.0, px = 0.0, py = 0.0;
+    double xi = 0.0, yi = 0.0, vxi = 0.0, vyi = 0.0, Voli = 0.0, mi = 1.0, p_i = 0.0, rhoh_i = 0.0;
+    double b11i = 1.0, b12i = 0.0, b21i = 0.0, b22i = 1.0;
+    int cx = 0, cy = 0;
+    bool near_wall = false;
+    if (active) {
+        xi = s.x[i]; yi = s.y[i]; vxi = s.vx[i]; vyi = s.vy[i];
+        Voli = t.Vol[i]; mi = s.mass[i]; p_i = t.ph[i]; rhoh_i = t.rhoh[i];
+        b11i = t.b11[i]; b12i = t.b12[i]; b21i = t.b21[i]; b22i = t.b22[i];
+        const int nn = t.nl_cnt[tid];
+        for (int m = 0; m < nn; ++m) {
+            const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+            const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+            const double ex = dx * inv_r, ey = dy * inv_r;
+            const double dW = spline_dW(ph.kc, r);
+            const double Volj = t.Vol[k];
+            const double tx = (b11i + t.b11[k]) * ex + (b12i + t.b12[k]) * ey;
+            const double ty = (b21i + t.b21[k]) * ex + (b22i + t.b22[k]) * ey;
+            const double eBe = ex * tx + ey * ty;
+            const double vxj = s.vx[k], vyj = s.vy[k];
+            const double dWVj = dW * Volj;
+            // viscous
+            const double coeff = eBe * ph.mu * dWVj / (r + 0.01 * h);
+            ax += coeff * (vxi - vxj);
+            ay += coeff * (vyi - vyj);
+            // transport
+            ix -= dWVj * tx;
+            iy -= dWVj * ty;
+            // pressure (Riemann-dissipated face pressure)
+            const double p_j = t.ph[k];
+            const double rho_bar = 0.5 * (rhoh_i + t.rhoh[k]);
+            const double un_l = vxi * ex + vyi * ey, un_r = vxj * ex + vyj * ey;
+            const double beta = riemann_beta(un_l, un_r, ph.c_f);
+            const double p_avg = 0.5 * (p_i + p_j);
+            const double p_star = p_avg + 0.5 * beta * rho_bar * (un_l - un_r);
+            const double p_face = 0.5 * (p_avg + p_star);
+            px -= (p_face * tx) * dWVj;
+            py -= (p_face * ty) * dWVj;
+        }
+        cell_of(g, xi, yi, cx, cy);
+        near_wall = w.row_any[cy] != 0;
+        if (near_wall) {
+            sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
+                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double r2 = dx * dx + dy * dy;
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                    const double r = sqrt(r2), inv_r = 1.0 / r;
+                    const double ex = dx * inv_r, ey = dy * inv_r;
+                    const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
+                    const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
+                    const double eBe = ex * tx + ey * ty;
+                    const double coeff = 4.0 * eBe * ph.mu * dWVj / (r + 0.01 * h);
+                    ax += coeff * (vxi - w.vx[k]);
+                    ay += coeff * (vyi - w.vy[k]);
+                    ix -= 2.0 * dWVj * tx;
+                    iy -= 2.0 * dWVj * ty;
+                }
+            });
+        }
+    }
+    ax = group_sum<LPP>(ax);
+    ay = group_sum<LPP>(ay);
+    ix = group_sum<LPP>(ix);
+    iy = group_sum<LPP>(iy);
+    const double fpx = ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
+    const double fpy = ay * Voli;
+    if (active && near_wall) {
+        const double acx = fpx / mi, acy = fpy / mi;
+        sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
+            const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+            const double r2 = dx * dx + dy * dy;
+            if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                const double r = sqrt(r2), inv_r = 1.0 / r;
+                const double ex = dx * inv_r, ey = dy * inv_r;
+                const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
+                const double face = -(acx * ex + acy * ey);
+                const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
+                const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
+                px -= (p_i + p_wall) * dWVj * tx;
+                py -= (p_i + p_wall) * dWVj * ty;
+            }
+        });
+    }
+    px = group_sum<LPP>(px);
+    py = group_sum<LPP>(py);
+    if (active && sub == 0) {
+        const double dt = clk->dt;
+        const double fx = px * Voli, fy = py * Voli;
+        const double inv_m = 1.0 / mi;
+        const double vxn = vxi + (fpx + fx) * inv_m * dt;
+        const double vyn = vyi + (fpy + fy) * inv_m * dt;
+        double sx, sy;
+        transport_shift(ix, iy, h, ph.tc, sx, sy);
+        double xo = xi + sx, yo = yi + sy;
+        xo += 0.5 * dt * vxi;
+        yo += 0.5 * dt * vyi;
+        xo += 0.5 * dt * vxn;
+        yo += 0.5 * dt * vyn;
+        t.xn[i] = g.periodic ? wrap_x(xo, ph.DL) : xo;  // a slab wraps when particles change owner
+        t.yn[i] = yo;
+        t.vxn[i] = vxn;
+        t.vyn[i] = vyn;
+        t.fpx[i] = fpx;
+        t.fpy[i] = fpy;
+        t.fx[i] = fx;
+        t.fy[i] = fy;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass E: continuity rate with the kicked velocities (integration_2nd, sph_physics_mex.c:1076-1116),
+// final half-step of rho and EOS (:1440-1450), per-block max |v|^2 over owned particles for the next
+// dt (SPH_Poiseuille.m:521) and -- single-GPU -- the cell histogram of the end-of-step positions
+// (neighbour rebuild, the K0 insert of mex/sph_neighbor_search_mex.c:269-296).
+// ---------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, Grid g, Phys ph,
+                                                       FluidSet s, FluidTmp t, Walls w, int do_hist)
+{
+    if (!clk->run[q]) return;
+    const int n = clk->n;
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    const int i = tid / LPP, sub = tid % LPP;
+    const bool active = i < n;
+    double rate = 0.0, v2 = 0.0;
+    double vxi = 0.0, vyi = 0.0, xi = 0.0;
+    if (active) {
+        xi = s.x[i];
+        const double yi = s.y[i];
+        vxi = t.vxn[i];
+        vyi = t.vyn[i];
+        const int nn = t.nl_cnt[tid];
+        for (int m = 0; m < nn; ++m) {
+            const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+            const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+            const double ex = dx * inv_r, ey = dy * inv_r;
+            const double u_jump = (vxi - t.vxn[k]) * ex + (vyi - t.vyn[k]) * ey;
+            rate += u_jump * spline_dW(ph.kc, r) * t.Vol[k];
+        }
+        int cx, cy;
+        cell_of(g, xi, yi, cx, cy);
+        if (w.row_any[cy]) {
+            sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
+                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double r2 = dx * dx + dy * dy;
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                    const double r = sqrt(r2), inv_r = 1.0 / r;
+                    const double ex = dx * inv_r, ey = dy * inv_r;
+                    const double vjx = 2.0 * w.vx[k] - vxi, vjy = 2.0 * w.vy[k] - vyi;
+                    const double jump = (vxi - vjx) * ex + (vyi - vjy) * ey;
+                    rate += jump * spline_dW(ph.kc, r) * w.Vol[k];
+                }
+            });
+        }
+    }
+    rate = group_sum<LPP>(rate);
+    if (active && sub == 0) {
+        const double dt = clk->dt;
+        const double rhoh = t.rhoh[i];
+        const double drho_new = rate * rhoh;
+        double rho = rhoh + drho_new * (0.5 * dt);
+        if (rho < 1e-10) rho = ph.rho0;
+        t.drhon[i] = drho_new;
+        t.rho_out[i] = rho;
+        t.p_out[i] = eos_pressure(rho, ph.rho0, ph.p0);
+        if (xi >= g.own_lo && xi < g.own_hi) {
+            v2 = vxi * vxi + vyi * vyi;
+            if (v2 != v2) v2 = INFINITY;  // NaN poisons the max on purpose
+        }
+        if (do_hist) {
+            int cx, cy;
+            cell_of(g, t.xn[i], t.yn[i], cx, cy);
+            const int c = cx * g.ncy + cy;
+            t.cellid[i] = c;
+            atomicAdd(&t.count[c], 1);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v2 = fmax(v2, __shfl_xor(v2, off));
+    __shared__ double s_max[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_max[0];
+        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_max[k]);
+        t.vpart[blockIdx.x] = m;
+    }
+}
+
+// standalone cell histogram (context creation, wall grid, slab steps): same binning as pass E
+__global__ __launch_bounds__(kBlock) void k_bin(const Clock *clk, int q, Grid g, int n_fixed, const double *x,
+                                                const double *y, int *cellid, int *count)
+{
+    if (clk && !clk->run[q]) return;
+    const int n = clk ? clk->n : n_fixed;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int cx, cy;
+    cell_of(g, x[i], y[i], cx, cy);
+    const int c = cx * g.ncy + cy;
+    cellid[i] = c;
+    atomicAdd(&count[c], 1);
+}
+
+// block-wide exclusive scan of one int per thread (kScanBlock threads); returns the block total
+__device__ __forceinline__ int block_exclusive_scan(int v, int &total, int *s_wave /*[17]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const int ws = lane < kScanBlock / 64 ? s_wave[lane] : 0;
+        int winc = ws;
+#pragma unroll
+        for (int off = 1; off < kScanBlock / 64; off <<= 1) {
+            const int o = __shfl_up(winc, off);
+            if (lane >= off) winc += o;
+        }
+        if (lane < kScanBlock / 64) s_wave[lane] = winc - ws;  // exclusive wave offsets
+        if (lane == kScanBlock / 64 - 1) s_wave[kScanBlock / 64] = winc;
+    }
+    __syncthreads();
+    const int res = s_wave[wave] + inc - v;
+    total = s_wave[kScanBlock / 64];
+    __syncthreads();
+    return res;
+}
+
+// exclusive scan of count[0..n) into start[0..n], by one block
+__device__ __forceinline__ void scan_counts(const int *count, int *start, int n)
+{
+    __shared__ int s_wave[kScanBlock / 64 + 1];
+    int carry = 0;
+    for (int base = 0; base < n; base += kScanBlock) {
+        const int idx = base + (int)threadIdx.x;
+        const int v = idx < n ? count[idx] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, total, s_wave);
+        if (idx < n) start[idx] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) start[n] = carry;
+}
+
+// big grids: tile-local exclusive scan (one 1024-cell tile per block) + tile sums
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const Clock *clk, int q, const int *count, int *start,
+                                                           int *tile_sum, int n)
+{
+    if (clk && !clk->run[q]) return;
+    __shared__ int s_wave[kScanBlock / 64 + 1];
+    const int idx = blockIdx.x * kScanBlock + (int)threadIdx.x;
+    const int v = idx < n ? count[idx] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, total, s_wave);
+    if (idx < n) start[idx] = ex;
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_add(const Clock *clk, int q, int *start, const int *tile_off,
+                                                         int n, int n_tiles)
+{
+    if (clk && !clk->run[q]) return;
+    const int idx = blockIdx.x * kScanBlock + (int)threadIdx.x;
+    if (idx < n) start[idx] += tile_off[blockIdx.x];
+    if (idx == 0) start[n] = tile_off[n_tiles];
+}
+
+// Step kernel 5: finish the clock of this step (vmax -> next dt, t += dt, stop test) and scan the
+// cell histogram (small grids) or the tile sums (big grids).  Single block.
+//   vmax_global: slab mode -- the all-reduced max |v| replaces the local reduction.
+__global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Phys ph, int n_vpart,
+                                                           const double *vpart, const double *vmax_global,
+                                                           const int *flags, const int *count,
+                                                           int *start_next, int n_scan, const int *n_new)
+{
+    if (!clk->run[q]) {
+        if (threadIdx.x == 0) clk->run[1 - q] = 0;
+        return;
+    }
+    double m = 0.0;
+    if (!vmax_global)
+        for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    __shared__ double s_m[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
+        Clock c = *clk;
+        c.vmax = vmax_global ? *vmax_global : sqrt(m);  // max of sqrt == sqrt of max (monotone)
+        c.t += c.dt;                                    // SPH_Poiseuille.m:267
+        c.dt_last = c.dt;
+        c.step += 1;
+        if (c.steps_left > 0) c.steps_left -= 1;
+        if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
+        if (*flags) c.status = SPHX_ERR_GRID;  // neighbour-list / slab-buffer overflow
+        if (n_new) c.n = *n_new;
+        c.dt = next_dt(c, ph);
+        c.run[1 - q] = loop_continues(c) ? 1 : 0;
+        *clk = c;
+    }
+    if (count) scan_counts(count, start_next, n_scan);
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_only(const Clock *clk, int q, const int *count, int *start, int n)
+{
+    if (clk && !clk->run[q]) return;
+    scan_counts(count, start, n);
+}
+
+// reduce per-block max |v|^2 to max |v| (slab: input of the all-reduce); single block
+__global__ __launch_bounds__(kScanBlock) void k_vmax_reduce(const Clock *clk, int q, int n_vpart, const double *vpart,
+                                                            double *vmax_out)
+{
+    if (clk && !clk->run[q]) { if (threadIdx.x == 0) *vmax_out = 0.0; return; }
+    double m = 0.0;
+    for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    __shared__ double s_m[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
+        *vmax_out = sqrt(m);
+    }
+}
+
+// Step kernel 6: place every particle index into its cell range (arrival order, made canonical by
+// k_reorder).  atomicSub counts the histogram back down to zero, ready for the next step.
+__global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int n_fixed, const int *cellid,
+                                                    int *count, const int *start_next, int *perm)
+{
+    if (clk && !clk->run[q]) return;
+    const int n = clk ? clk->n : n_fixed;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int c = cellid[i];
+    const int k = atomicSub(&count[c], 1) - 1;
+    perm[start_next[c] + k] = i;
+}
+
+struct ReorderArgs {
+    int nd;
+    const double *src[8];
+    double *dst[8];
+    const int *id_src;
+    int *id_dst;
+    int *src_of;
+};
+
+// Step kernel 7: canonical rank inside the cell (ascending particle id -> an order that does not
+// depend on arrival order, launch shape or domain decomposition) and the gather of every persistent
+// field into the new ordering.
+__global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int n_fixed, const int *cellid,
+                                                    const int *start_next, const int *perm, ReorderArgs a)
+{
+    if (clk && !clk->run[q]) return;
+    const int n = clk ? clk->n : n_fixed;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int c = cellid[i];
+    const int lo = start_next[c], hi = start_next[c + 1];
+    const int my_id = a.id_src[i];
+    int rank = 0;
+    for (int k = lo; k < hi; ++k) {
+        const int o = perm[k];
+        const int oid = a.id_src[o];
+        rank += (oid < my_id || (oid == my_id && o < i)) ? 1 : 0;  // tie (periodic images in a slab): by slot
+    }
+    const int dst = lo + rank;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+        if (f < a.nd) a.dst[f][dst] = a.src[f][i];
+    a.id_dst[dst] = my_id;
+    if (a.src_of) a.src_of[dst] = i;
+}
+
+__global__ __launch_bounds__(kBlock) void k_iota(int n, int *a, int base)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) a[i] = base + i;
+}
+
+__global__ __launch_bounds__(kBlock) void k_wrap_x(int n, double *x, double DL)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) x[i] = wrap_x(x[i], DL);
+}
+
+__global__ __launch_bounds__(kBlock) void k_wall_volume(int n, const double *mass, double rho0, double *Vol)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) Vol[i] = mass[i] / rho0;  // walls keep rho = rho0 (sph_physics_mex.c:214-216,233)
+}
+
+__global__ void k_row_any(Grid g, const int *wstart, int *row_any)
+{
+    const int cy = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cy >= g.ncy) return;
+    int any = 0;
+    for (int r = max(cy - 1, 0); r <= min(cy + 1, g.ncy - 1) && !any; ++r)
+        for (int cx = 0; cx < g.ncx; ++cx) {
+            const int c = cx * g.ncy + r;
+            if (wstart[c + 1] > wstart[c]) { any = 1; break; }
+        }
+    row_any[cy] = any;
+}
+
+// initial max |v| over owned particles (vecnorm over the fluid, SPH_Poiseuille.m:521); single block
+__global__ __launch_bounds__(kScanBlock) void k_vmax_init(Clock *clk, Grid g, const double *x, const double *vx,
+                                                          const double *vy, double *vmax_out)
+{
+    const int n = clk->n;
+    double m = 0.0;
+    for (int k = threadIdx.x; k < n; k += kScanBlock) {
+        if (!(x[k] >= g.own_lo && x[k] < g.own_hi)) continue;
+        double v2 = vx[k] * vx[k] + vy[k] * vy[k];
+        if (v2 != v2) v2 = INFINITY;
+        m = fmax(m, v2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    __shared__ double s_m[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
+        clk->vmax = sqrt(m);
+        if (vmax_out) *vmax_out = sqrt(m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// monitors and pair-list emission on the current ordering
+// ---------------------------------------------------------------------------------------------
+
+// wall shear (sph_physics_mex.c:1713-1742): new neighbour structure, new pos/vel, Vol/B of the step
+// that just finished (reached through src_of).  Per-block partial sums, reduced by k_tau_final.
+__global__ __launch_bounds__(kBlock) void k_wall_shear(const Clock *clk, Grid g, Phys ph, FluidSet s, FluidTmp t,
+                                                       Walls w, double *part /*[2*grid]*/)
+{
+    const int n = clk->n;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double fb = 0.0, ft = 0.0;
+    if (i < n) {
+        const double xi = s.x[i], yi = s.y[i];
+        int cx, cy;
+        cell_of(g, xi, yi, cx, cy);
+        if (w.row_any[cy] && xi >= g.own_lo && xi < g.own_hi) {
+            const int o = t.src_of[i];
+            const double Voli = t.Vol[o];
+            const double b11 = t.b11[o], b12 = t.b12[o], b21 = t.b21[o], b22 = t.b22[o];
+            const double vxi = s.vx[i];
+            sweep<1>(g, w.start, cx, cy, 0, [&](int k) {
+                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double r2 = dx * dx + dy * dy;
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                    const double r = sqrt(r2);
+                    const double ex = dx / r, ey = dy / r;
+                    const double eBe = ex * (b11 * ex + b12 * ey) + ey * (b21 * ex + b22 * ey);
+                    const double f = 4.0 * ph.mu * eBe * spline_dW(ph.kc, r) * w.Vol[k] * (vxi - w.vx[k]) /
+                                     (r + 0.01 * ph.kc.h) * Voli;
+                    const double yj = w.y[k];
+                    if (yj <= 0.0) fb += f;
+                    else if (yj >= ph.DH) ft += f;
+                }
+            });
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        fb += __shfl_xor(fb, off);
+        ft += __shfl_xor(ft, off);
+    }
+    __shared__ double sb[kBlock / 64], st[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = fb; st[threadIdx.x >> 6] = ft; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < kBlock / 64; ++k) { a += sb[k]; b += st[k]; }
+        part[2 * blockIdx.x] = a;
+        part[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_tau_final(int nblk, const double *part, double DL, double *out)
+{
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += kScanBlock) { a += part[2 * k]; b += part[2 * k + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    __shared__ double sa[kScanBlock / 64], sb[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0.0; b = 0.0;
+        for (int k = 0; k < kScanBlock / 64; ++k) { a += sa[k]; b += sb[k]; }
+        out[0] = -a / DL;  // the caller sums slabs; -sum/DL is linear
+        out[1] = -b / DL;
+    }
+}
+
+// Pair emission in the MEX convention (sph_neighbor_search_mex.c:353-383): a fluid-fluid pair is
+// produced once, from the particle with the smaller ORIGINAL index; fluid-wall pairs always.
+// MODE 0: count into cnt[orig]; MODE 1: write at off[orig].  (single-GPU contexts only)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_pairs(const Clock *clk, Grid g, Phys ph, FluidSet s, Walls w, int *cnt,
+                                                  const int *off, double *o_i, double *o_j, double *o_dx,
+                                                  double *o_dy, double *o_r, double *o_W, double *o_dW)
+{
+    const int nf = clk->n;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nf) return;
+    const double xi = s.x[i], yi = s.y[i];
+    const int a = s.id[i];
+    int cx, cy;
+    cell_of(g, xi, yi, cx, cy);
+    int n = 0;
+    const int base = MODE ? off[a] : 0;
+    auto emit = [&](int b, double dx, double dy, double r2) {
+        if (MODE) {
+            const double r = sqrt(r2);
+            double W, dW;
+            spline(ph.kc, r, W, dW);
+            const int p = base + n;
+            o_i[p] = (double)(a + 1);
+            o_j[p] = (double)(b + 1);
+            o_dx[p] = dx; o_dy[p] = dy; o_r[p] = r; o_W[p] = W; o_dW[p] = dW;
+        }
+        ++n;
+    };
+    sweep<1>(g, s.start, cx, cy, 0, [&](int k) {
+        const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+        const double r2 = dx * dx + dy * dy;
+        if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+            const int b = s.id[k];
+            if (b > a) emit(b, dx, dy, r2);
+        }
+    });
+    if (w.row_any[cy]) {
+        sweep<1>(g, w.start, cx, cy, 0, [&](int k) {
+            const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+            const double r2 = dx * dx + dy * dy;
+            if (r2 > kR2Min && r2 < ph.kc.rcut2) emit(w.id[k], dx, dy, r2);
+        });
+    }
+    if (!MODE) cnt[a] = n;
+}
+
+// scatter a sorted field back to the caller's row numbering
+__global__ __launch_bounds__(kBlock) void k_unsort(int n, const int *id, const double *src, double *dst)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[id[i]] = src[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill(int n, double *dst, double v)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// x-slab halo exchange (multi-GPU): pack the end-of-step state of OWNED particles into
+//   keep  : still inside [own_lo, own_hi)            -> compacted in place for the next step
+//   sendL : x_new < own_lo + halo_w  (shifted by shift_l: +DL on the first slab)
+//   sendR : x_new >= own_hi - halo_w (shifted by shift_r: -DL on the last slab)
+// A message is double[1 + 7*cap]: count, then x,y,vx,vy,drho,mass,id blocks of `cap`.
+// Particles that were halo copies at the start of the step are dropped: their owner sends fresh ones.
+// ---------------------------------------------------------------------------------------------
+struct SlabPack {
+    double *send_l, *send_r;   // device message buffers
+    int *counters;             // [3]: keep, left, right (zeroed by k_slab_unpack of the previous step)
+    double *kx, *ky, *kvx, *kvy, *kdrho, *kmass;  // keep arrays (compacted)
+    int *kid;
+    double halo_w, shift_l, shift_r;
+    int msg_cap, keep_cap;
+};
+
+__device__ __forceinline__ void msg_put(double *msg, int cap, int slot, double x, double y, double vx, double vy,
+                                        double drho, double mass, int id)
+{
+    double *b = msg + 1;
+    b[slot] = x;
+    b[(size_t)cap + slot] = y;
+    b[2 * (size_t)cap + slot] = vx;
+    b[3 * (size_t)cap + slot] = vy;
+    b[4 * (size_t)cap + slot] = drho;
+    b[5 * (size_t)cap + slot] = mass;
+    b[6 * (size_t)cap + slot] = (double)id;
+}
+
+__global__ __launch_bounds__(kBlock) void k_slab_pack(const Clock *clk, int q, Grid g, FluidSet s, FluidTmp t,
+                                                      SlabPack p)
+{
+    if (!clk->run[q]) return;
+    const int n = clk->n;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double x_ref = s.x[i];
+    if (!(x_ref >= g.own_lo && x_ref < g.own_hi)) return;  // halo copy
+    const double xn = t.xn[i], yn = t.yn[i], vxn = t.vxn[i], vyn = t.vyn[i], dr = t.drhon[i], m = s.mass[i];
+    const int id = s.id[i];
+    if (xn >= g.own_lo && xn < g.own_hi) {
+        const int k = atomicAdd(&p.counters[0], 1);
+        if (k < p.keep_cap) {
+            p.kx[k] = xn; p.ky[k] = yn; p.kvx[k] = vxn; p.kvy[k] = vyn; p.kdrho[k] = dr; p.kmass[k] = m; p.kid[k] = id;
+        } else atomicOr(t.flags, 2);
+    }
+    if (xn < g.own_lo + p.halo_w) {
+        const int k = atomicAdd(&p.counters[1], 1);
+        if (k < p.msg_cap) msg_put(p.send_l, p.msg_cap, k, xn + p.shift_l, yn, vxn, vyn, dr, m, id);
+        else atomicOr(t.flags, 2);
+    }
+    if (xn >= g.own_hi - p.halo_w) {
+        const int k = atomicAdd(&p.counters[2], 1);
+        if (k < p.msg_cap) msg_put(p.send_r, p.msg_cap, k, xn + p.shift_r, yn, vxn, vyn, dr, m, id);
+        else atomicOr(t.flags, 2);
+    }
+}
+
+// one thread: publish the message counts after the pack kernel
+__global__ void k_slab_seal(const Clock *clk, int q, SlabPack p)
+{
+    const bool run = clk->run[q] != 0;
+    p.send_l[0] = run ? (double)min(p.counters[1], p.msg_cap) : -1.0;
+    p.send_r[0] = run ? (double)min(p.counters[2], p.msg_cap) : -1.0;
+}
+
+// append the received halo/migrant particles behind the kept ones; writes the new particle count.
+__global__ __launch_bounds__(kBlock) void k_slab_unpack(const Clock *clk, int q, SlabPack p, const double *recv_l,
+                                                        const double *recv_r, int *n_new, int *flags)
+{
+    if (!clk->run[q]) return;
+    const int nk = min(p.counters[0], p.keep_cap);
+    const int nl = (int)recv_l[0], nr = (int)recv_r[0];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (nl < 0 || nr < 0 || nk + nl + nr > p.keep_cap) {
+        if (i == 0) { atomicOr(flags, 2); *n_new = min(nk, p.keep_cap); }
+        return;
+    }
+    if (i == 0) *n_new = nk + nl + nr;
+    const int cap = p.msg_cap;
+    if (i < nl + nr) {
+        const double *b = (i < nl ? recv_l : recv_r) + 1;
+        const int sl = i < nl ? i : i - nl;
+        const int d = nk + i;
+        p.kx[d] = b[sl];
+        p.ky[d] = b[(size_t)cap + sl];
+        p.kvx[d] = b[2 * (size_t)cap + sl];
+        p.kvy[d] = b[3 * (size_t)cap + sl];
+        p.kdrho[d] = b[4 * (size_t)cap + sl];
+        p.kmass[d] = b[5 * (size_t)cap + sl];
+        p.kid[d] = (int)b[6 * (size_t)cap + sl];
+    }
+}
+
+// one thread, after the rebuild of a slab step: zero the pack counters for the next step
+__global__ void k_slab_reset(const Clock *clk, int q, int *counters)
+{
+    if (!clk->run[q]) return;
+    counters[0] = 0; counters[1] = 0; counters[2] = 0;
+}
+
+}  // namespace sphx

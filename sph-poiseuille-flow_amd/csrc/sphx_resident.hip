@@ -1,794 +1,45 @@
-// sphx_resident.hip -- device-resident SPH step for MI355X (gfx950): the whole inner loop of
-// SPH_Poiseuille.m:250-292 (density_correction -> viscous_force + gravity -> transport_correction ->
-// verlet_time_step -> integration_verlet -> periodic wrap -> neighbour rebuild) as seven HIP kernels
-// per step with no host round trip, plus the monitors and the MEX-convention pair-list emitter.
-//
-// Design (DESIGN.md has the long form):
-//   * particles live in SoA double arrays sorted by cell, cell id = cx*ncy + cy (y fastest): the 3x3
-//     neighbourhood of a cell is three contiguous index ranges, and an x-slab of the channel is one
-//     contiguous range (multi-GPU halo = contiguous copies);
-//   * cells are exactly periodic in x: ncx = floor(DL/2h), width DL/ncx >= 2h, so the wrapped 3x3
-//     sweep sees every min-image neighbour and the reference's ghost entries + seen_neighbor
-//     (mex/sph_neighbor_search_mex.c:282-295,342,383) are not needed; the accepted set is the same
-//     {r^2 > 1e-24, r^2 < (2h)^2} (:368);
-//   * every pair sum is written as a per-particle gather (each fluid-fluid update of
-//     mex/sph_physics_mex.c is symmetric under i<->j), so there are no atomics in the physics and the
-//     result is bitwise reproducible run to run;
-//   * LPP lanes of a wavefront cooperate on one particle's neighbour ring and combine with
-//     __shfl_xor (wave64), which is what fills the chip at the 5-60 k particle configs;
-//   * geometry is frozen for a step: all four passes use the positions the cell grid was built from
-//     (the reference keeps dx,dy,r,W,dW of the list built at the end of the previous step);
-//   * dt, t, step count and the stop condition live in a device-side clock, so steps can be captured
-//     into a hipGraph and replayed.
+// sphx_resident.hip -- host side of the device-resident SPH step (include/sphx.h section 2):
+// context creation (cell grid build on device), the step loop as hipGraph replays, download, monitors,
+// MEX-convention pair-list emission, per-kernel HIP-event timing, and the x-slab (multi-GPU) entry
+// points.  The kernels are in sphx_kernels.hpp.
 #include <algorithm>
 #include <cmath>
-#include <map>
+#include <limits>
 
 #include "sphx_common.hpp"
-#include "sphx_device.hpp"
+#include "sphx_kernels.hpp"
 
 namespace sphx {
-namespace {
 
-constexpr int kBlock = 256;
-constexpr int kScanBlock = 1024;
-
-struct Grid {
-    int ncx, ncy, ncells;
-    double DL, y0, inv_csx, inv_csy;
-};
-
-struct Phys {
-    KernelConst kc;
-    double rho0, inv_sigma0, mu, p0, c_f, g, tc, nu, DL, DH, w0;
-};
-
-// Device-side clock: replaces the host variables state.t/state.step/dt_step/remain of
-// SPH_Poiseuille.m:247-267 so the loop needs no host decisions.
-struct Clock {
-    double t, dt, dt_last, t_target, t_end, vmax;
-    long long step, steps_left;  // steps_left < 0: unlimited
-    int run[2];                  // run[q]: the step slot of parity q executes
-    int status;
-    int pad;
-};
-
-struct FluidSet {  // persistent per-particle state, sorted by cell
-    double *x, *y, *vx, *vy, *drho, *mass;
-    int *id;
-    int *start;  // [ncells+1] cell ranges of this ordering
-};
-
-struct FluidTmp {
-    double *xn, *yn, *vxn, *vyn, *drhon;                   // end-of-step state, pre-sort order
-    double *rho, *Vol, *rhoh, *ph, *b11, *b12, *b21, *b22;  // per-step fields
-    double *fpx, *fpy, *fx, *fy, *rho_out, *p_out;         // outputs of the step
-    int *cellid, *count, *perm, *src_of;
-    double *vpart;  // per-block max |v|^2 of pass E
-};
-
-struct Walls {
-    const double *x, *y, *Vol, *vx, *vy;
-    const int *id;
-    const int *start;  // [ncells+1]
-    const int *row_any;  // [ncy] 1 when rows cy-1..cy+1 hold any wall particle
-    int n;
-};
-
-__device__ __forceinline__ void cell_of(const Grid &g, double x, double y, int &cx, int &cy)
-{
-    cx = (int)(x * g.inv_csx);
-    cx = min(max(cx, 0), g.ncx - 1);
-    cy = (int)floor((y - g.y0) * g.inv_csy);
-    cy = min(max(cy, 0), g.ncy - 1);
-}
-
-__device__ __forceinline__ double wrap_x(double x, double DL) { return x - floor(x / DL) * DL; }
-
-template <int LPP>
-__device__ __forceinline__ double group_sum(double v)
-{
-#pragma unroll
-    for (int off = LPP / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-// Visit the candidates of the three cell columns around (cx,cy): body(k, xi_shifted) with
-// dx = xi_shifted - x[k] being the min-image separation.
-template <int LPP, typename Body>
-__device__ __forceinline__ void sweep(const Grid &g, const int *__restrict__ start, int cx, int cy,
-                                      int sub, double xi, Body &&body)
-{
-    const int cylo = max(cy - 1, 0), cyhi = min(cy + 1, g.ncy - 1);
-#pragma unroll
-    for (int ox = -1; ox <= 1; ++ox) {
-        int col = cx + ox;
-        double shift = 0.0;
-        if (col < 0) { col += g.ncx; shift = -g.DL; }
-        else if (col >= g.ncx) { col -= g.ncx; shift = g.DL; }
-        const int base = col * g.ncy;
-        const int lo = start[base + cylo], hi = start[base + cyhi + 1];
-        const double xis = xi - shift;
-        for (int k = lo + sub; k < hi; k += LPP) body(k, xis);
-    }
-}
-
-__device__ __forceinline__ double next_dt(const Clock &c, const Phys &ph)
-{  // SPH_Poiseuille.m:519-527 with remain of :252
-    const double remain = fmin(c.t_target - c.t, c.t_end - c.t);
-    const double h = ph.kc.h;
-    const double dt_acoustic = 0.25 * h / fmax(ph.c_f + c.vmax, 1e-12);
-    const double dt_viscous = 0.125 * h * h / fmax(ph.nu, 1e-12);
-    const double dt_body = 0.25 * sqrt(h / fmax(fabs(ph.g), 1e-12));
-    const double dt = fmin(fmin(dt_acoustic, dt_viscous), fmin(dt_body, remain));
-    return fmax(dt, 1e-12);
-}
-
-__device__ __forceinline__ bool loop_continues(const Clock &c)
-{  // while state.t < target_time - 1e-12 (SPH_Poiseuille.m:250) and step budget left
-    return (c.t < c.t_target - 1e-12) && (c.steps_left != 0) && (c.status == 0);
-}
-
-// one thread: arm the clock for an advance call
-__global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_steps, int q0)
-{
-    Clock c = *clk;
-    c.t_target = fmin(t_target, c.t_end);  // target_time = min(t + output_interval, t_end), SPH_Poiseuille.m:248
-    c.steps_left = max_steps > 0 ? max_steps : -1;
-    if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
-    c.dt = next_dt(c, ph);
-    const int go = loop_continues(c) ? 1 : 0;
-    c.run[q0] = go;
-    c.run[1 - q0] = 0;
-    *clk = c;
-}
-
-// ---------------------------------------------------------------------------------------------
-// pass A: number-density summation -> rho, Vol (mex/sph_physics_mex.c:188-234) and the half-step
-// density/pressure of integration_1st's pre-pass (:857-862), which only needs own-particle data.
-// ---------------------------------------------------------------------------------------------
-template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Grid g, Phys ph, int nf,
-                                                    FluidSet s, FluidTmp t, Walls w)
-{
-    if (!clk->run[q]) return;
-    const int tid = blockIdx.x * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
-    const bool active = i < nf;
-    double s_in = 0.0, s_ct = 0.0;
-    if (active) {
-        const double xi = s.x[i], yi = s.y[i];
-        int cx, cy;
-        cell_of(g, xi, yi, cx, cy);
-        sweep<LPP>(g, s.start, cx, cy, sub, xi, [&](int k, double xis) {
-            const double dx = xis - s.x[k], dy = yi - s.y[k];
-            const double r2 = dx * dx + dy * dy;
-            if (r2 > kR2Min && r2 < ph.kc.rcut2) s_in += spline_W(ph.kc, sqrt(r2));
-        });
-        if (w.row_any[cy]) {
-            sweep<LPP>(g, w.start, cx, cy, sub, xi, [&](int k, double xis) {
-                const double dx = xis - w.x[k], dy = yi - w.y[k];
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, sqrt(r2)) * w.Vol[k];
-            });
-        }
-    }
-    s_in = group_sum<LPP>(s_in);
-    s_ct = group_sum<LPP>(s_ct);
-    if (active && sub == 0) {
-        const double m = s.mass[i];
-        const double rho = density_from_sigma(ph.w0 + s_in, s_ct, m, ph.rho0, ph.inv_sigma0);
-        const double dt = clk->dt;
-        double rhoh = rho + 0.5 * dt * s.drho[i];
-        if (rhoh < 1e-10) rhoh = ph.rho0;
-        t.rho[i] = rho;
-        t.Vol[i] = m / rho;
-        t.rhoh[i] = rhoh;
-        t.ph[i] = eos_pressure(rhoh, ph.rho0, ph.p0);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pass B: kernel-gradient-correction matrix A -> blended pseudo-inverse B
-// (mex/sph_physics_mex.c:239-366)
-// ---------------------------------------------------------------------------------------------
-template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g, Phys ph, int nf,
-                                                FluidSet s, FluidTmp t, Walls w)
-{
-    if (!clk->run[q]) return;
-    const int tid = blockIdx.x * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
-    const bool active = i < nf;
-    double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
-    if (active) {
-        const double xi = s.x[i], yi = s.y[i];
-        int cx, cy;
-        cell_of(g, xi, yi, cx, cy);
-        auto term = [&](double dx, double dy, double r2, double Volj) {
-            const double r = sqrt(r2), inv_r = 1.0 / r;
-            const double ex = dx * inv_r, ey = dy * inv_r;
-            const double fxj = spline_dW(ph.kc, r) * Volj;
-            a11 -= dx * (fxj * ex);
-            a12 -= dx * (fxj * ey);
-            a21 -= dy * (fxj * ex);
-            a22 -= dy * (fxj * ey);
-        };
-        sweep<LPP>(g, s.start, cx, cy, sub, xi, [&](int k, double xis) {
-            const double dx = xis - s.x[k], dy = yi - s.y[k];
-            const double r2 = dx * dx + dy * dy;
-            if (r2 > kR2Min && r2 < ph.kc.rcut2) term(dx, dy, r2, t.Vol[k]);
-        });
-        if (w.row_any[cy]) {
-            sweep<LPP>(g, w.start, cx, cy, sub, xi, [&](int k, double xis) {
-                const double dx = xis - w.x[k], dy = yi - w.y[k];
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) term(dx, dy, r2, w.Vol[k]);
-            });
-        }
-    }
-    a11 = group_sum<LPP>(a11);
-    a12 = group_sum<LPP>(a12);
-    a21 = group_sum<LPP>(a21);
-    a22 = group_sum<LPP>(a22);
-    if (active && sub == 0) {
-        const Mat2 B = kgc_from_A(a11, a12, a21, a22);
-        t.b11[i] = B.m11;
-        t.b12[i] = B.m12;
-        t.b21[i] = B.m21;
-        t.b22[i] = B.m22;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pass CD: viscous force (+gravity) [sph_physics_mex.c:469-545, SPH_Poiseuille.m:392], transport
-// shift [:636-710], Riemann pressure force of integration_1st [:870-957], velocity kick
-// [:1400-1408] and both position half-drifts [:863-864,:1066-1069] + periodic wrap
-// [SPH_Poiseuille.m:570-577].  One sweep over the fluid ring serves all three operators because
-// they share e, dW, B_i+B_j; the wall ring is swept twice because the wall pressure needs the
-// complete viscous+gravity force of the particle first (p_wall uses force_prior_i, :931-934).
-// ---------------------------------------------------------------------------------------------
-template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid g, Phys ph, int nf,
-                                                   FluidSet s, FluidTmp t, Walls w)
-{
-    if (!clk->run[q]) return;
-    const int tid = blockIdx.x * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
-    const bool active = i < nf;
-    const double h = ph.kc.h;
-    double ax = 0.0, ay = 0.0, ix = 0.0, iy = 0.0, px = 0.0, py = 0.0;
-    double xi = 0.0, yi = 0.0, vxi = 0.0, vyi = 0.0, Voli = 0.0, mi = 1.0, p_i = 0.0, rhoh_i = 0.0;
-    double b11i = 1.0, b12i = 0.0, b21i = 0.0, b22i = 1.0;
-    int cx = 0, cy = 0;
-    bool near_wall = false;
-    if (active) {
-        xi = s.x[i]; yi = s.y[i]; vxi = s.vx[i]; vyi = s.vy[i];
-        Voli = t.Vol[i]; mi = s.mass[i]; p_i = t.ph[i]; rhoh_i = t.rhoh[i];
-        b11i = t.b11[i]; b12i = t.b12[i]; b21i = t.b21[i]; b22i = t.b22[i];
-        cell_of(g, xi, yi, cx, cy);
-        near_wall = w.row_any[cy] != 0;
-        sweep<LPP>(g, s.start, cx, cy, sub, xi, [&](int k, double xis) {
-            const double dx = xis - s.x[k], dy = yi - s.y[k];
-            const double r2 = dx * dx + dy * dy;
-            if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                const double r = sqrt(r2), inv_r = 1.0 / r;
-                const double ex = dx * inv_r, ey = dy * inv_r;
-                const double dW = spline_dW(ph.kc, r);
-                const double Volj = t.Vol[k];
-                const double tx = (b11i + t.b11[k]) * ex + (b12i + t.b12[k]) * ey;
-                const double ty = (b21i + t.b21[k]) * ex + (b22i + t.b22[k]) * ey;
-                const double eBe = ex * tx + ey * ty;
-                const double vxj = s.vx[k], vyj = s.vy[k];
-                const double dWVj = dW * Volj;
-                // viscous
-                const double coeff = eBe * ph.mu * dWVj / (r + 0.01 * h);
-                ax += coeff * (vxi - vxj);
-                ay += coeff * (vyi - vyj);
-                // transport
-                ix -= dWVj * tx;
-                iy -= dWVj * ty;
-                // pressure (Riemann-dissipated face pressure)
-                const double p_j = t.ph[k];
-                const double rho_bar = 0.5 * (rhoh_i + t.rhoh[k]);
-                const double un_l = vxi * ex + vyi * ey, un_r = vxj * ex + vyj * ey;
-                const double beta = riemann_beta(un_l, un_r, ph.c_f);
-                const double p_avg = 0.5 * (p_i + p_j);
-                const double p_star = p_avg + 0.5 * beta * rho_bar * (un_l - un_r);
-                const double p_face = 0.5 * (p_avg + p_star);
-                px -= (p_face * tx) * dWVj;
-                py -= (p_face * ty) * dWVj;
-            }
-        });
-        if (near_wall) {
-            sweep<LPP>(g, w.start, cx, cy, sub, xi, [&](int k, double xis) {
-                const double dx = xis - w.x[k], dy = yi - w.y[k];
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                    const double r = sqrt(r2), inv_r = 1.0 / r;
-                    const double ex = dx * inv_r, ey = dy * inv_r;
-                    const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
-                    const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
-                    const double eBe = ex * tx + ey * ty;
-                    const double coeff = 4.0 * eBe * ph.mu * dWVj / (r + 0.01 * h);
-                    ax += coeff * (vxi - w.vx[k]);
-                    ay += coeff * (vyi - w.vy[k]);
-                    ix -= 2.0 * dWVj * tx;
-                    iy -= 2.0 * dWVj * ty;
-                }
-            });
-        }
-    }
-    ax = group_sum<LPP>(ax);
-    ay = group_sum<LPP>(ay);
-    ix = group_sum<LPP>(ix);
-    iy = group_sum<LPP>(iy);
-    const double fpx = ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
-    const double fpy = ay * Voli;
-    if (active && near_wall) {
-        const double acx = fpx / mi, acy = fpy / mi;
-        sweep<LPP>(g, w.start, cx, cy, sub, xi, [&](int k, double xis) {
-            const double dx = xis - w.x[k], dy = yi - w.y[k];
-            const double r2 = dx * dx + dy * dy;
-            if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                const double r = sqrt(r2), inv_r = 1.0 / r;
-                const double ex = dx * inv_r, ey = dy * inv_r;
-                const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
-                const double face = -(acx * ex + acy * ey);
-                const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
-                const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
-                px -= (p_i + p_wall) * dWVj * tx;
-                py -= (p_i + p_wall) * dWVj * ty;
-            }
-        });
-    }
-    px = group_sum<LPP>(px);
-    py = group_sum<LPP>(py);
-    if (active && sub == 0) {
-        const double dt = clk->dt;
-        const double fx = px * Voli, fy = py * Voli;
-        const double inv_m = 1.0 / mi;
-        const double vxn = vxi + (fpx + fx) * inv_m * dt;
-        const double vyn = vyi + (fpy + fy) * inv_m * dt;
-        double sx, sy;
-        transport_shift(ix, iy, h, ph.tc, sx, sy);
-        double xo = xi + sx, yo = yi + sy;
-        xo += 0.5 * dt * vxi;
-        yo += 0.5 * dt * vyi;
-        xo += 0.5 * dt * vxn;
-        yo += 0.5 * dt * vyn;
-        t.xn[i] = wrap_x(xo, ph.DL);
-        t.yn[i] = yo;
-        t.vxn[i] = vxn;
-        t.vyn[i] = vyn;
-        t.fpx[i] = fpx;
-        t.fpy[i] = fpy;
-        t.fx[i] = fx;
-        t.fy[i] = fy;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pass E: continuity rate with the kicked velocities (integration_2nd, sph_physics_mex.c:1076-1116),
-// final half-step of rho and EOS (:1440-1450), per-block max |v|^2 for the next dt
-// (SPH_Poiseuille.m:521) and the cell histogram of the end-of-step positions (neighbour rebuild,
-// the K0 insert of mex/sph_neighbor_search_mex.c:269-296).
-// ---------------------------------------------------------------------------------------------
-template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, Grid g, Phys ph,
-                                                       int nf, FluidSet s, FluidTmp t, Walls w)
-{
-    if (!clk->run[q]) return;
-    const int tid = blockIdx.x * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
-    const bool active = i < nf;
-    double rate = 0.0, v2 = 0.0;
-    double vxi = 0.0, vyi = 0.0;
-    if (active) {
-        const double xi = s.x[i], yi = s.y[i];
-        vxi = t.vxn[i];
-        vyi = t.vyn[i];
-        int cx, cy;
-        cell_of(g, xi, yi, cx, cy);
-        sweep<LPP>(g, s.start, cx, cy, sub, xi, [&](int k, double xis) {
-            const double dx = xis - s.x[k], dy = yi - s.y[k];
-            const double r2 = dx * dx + dy * dy;
-            if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                const double r = sqrt(r2), inv_r = 1.0 / r;
-                const double ex = dx * inv_r, ey = dy * inv_r;
-                const double u_jump = (vxi - t.vxn[k]) * ex + (vyi - t.vyn[k]) * ey;
-                rate += u_jump * spline_dW(ph.kc, r) * t.Vol[k];
-            }
-        });
-        if (w.row_any[cy]) {
-            sweep<LPP>(g, w.start, cx, cy, sub, xi, [&](int k, double xis) {
-                const double dx = xis - w.x[k], dy = yi - w.y[k];
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                    const double r = sqrt(r2), inv_r = 1.0 / r;
-                    const double ex = dx * inv_r, ey = dy * inv_r;
-                    const double vjx = 2.0 * w.vx[k] - vxi, vjy = 2.0 * w.vy[k] - vyi;
-                    const double jump = (vxi - vjx) * ex + (vyi - vjy) * ey;
-                    rate += jump * spline_dW(ph.kc, r) * w.Vol[k];
-                }
-            });
-        }
-    }
-    rate = group_sum<LPP>(rate);
-    if (active && sub == 0) {
-        const double dt = clk->dt;
-        const double rhoh = t.rhoh[i];
-        const double drho_new = rate * rhoh;
-        double rho = rhoh + drho_new * (0.5 * dt);
-        if (rho < 1e-10) rho = ph.rho0;
-        t.drhon[i] = drho_new;
-        t.rho_out[i] = rho;
-        t.p_out[i] = eos_pressure(rho, ph.rho0, ph.p0);
-        v2 = vxi * vxi + vyi * vyi;
-        int cx, cy;
-        cell_of(g, t.xn[i], t.yn[i], cx, cy);
-        const int c = cx * g.ncy + cy;
-        t.cellid[i] = c;
-        atomicAdd(&t.count[c], 1);
-    }
-    // block max of |v|^2 (NaN poisons the max on purpose: v2 != v2 -> +inf)
-    if (v2 != v2) v2 = INFINITY;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v2 = fmax(v2, __shfl_xor(v2, off));
-    __shared__ double s_max[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v2;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double m = s_max[0];
-        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_max[k]);
-        t.vpart[blockIdx.x] = m;
-    }
-}
-
-// standalone cell histogram (context creation / wall grid): same binning as pass E's epilogue
-__global__ __launch_bounds__(kBlock) void k_bin(Grid g, int n, const double *x, const double *y,
-                                                int *cellid, int *count)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    int cx, cy;
-    cell_of(g, x[i], y[i], cx, cy);
-    const int c = cx * g.ncy + cy;
-    cellid[i] = c;
-    atomicAdd(&count[c], 1);
-}
-
-// block-wide exclusive scan of one int per thread (kScanBlock threads); returns the block total
-__device__ __forceinline__ int block_exclusive_scan(int v, int &total, int *s_wave /*[16]*/)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    if (wave == 0) {
-        int ws = lane < kScanBlock / 64 ? s_wave[lane] : 0;
-        int winc = ws;
-#pragma unroll
-        for (int off = 1; off < kScanBlock / 64; off <<= 1) {
-            const int o = __shfl_up(winc, off);
-            if (lane >= off) winc += o;
-        }
-        if (lane < kScanBlock / 64) s_wave[lane] = winc - ws;  // exclusive wave offsets
-        if (lane == kScanBlock / 64 - 1) s_wave[kScanBlock / 64] = winc;
-    }
-    __syncthreads();
-    const int res = s_wave[wave] + inc - v;
-    total = s_wave[kScanBlock / 64];
-    __syncthreads();
-    return res;
-}
-
-// exclusive scan of count[0..n) into start[0..n], single block (n_cells is small next to n_particles)
-__device__ __forceinline__ void scan_counts(const int *count, int *start, int n)
-{
-    __shared__ int s_wave[kScanBlock / 64 + 1];
-    int carry = 0;
-    for (int base = 0; base < n; base += kScanBlock) {
-        const int idx = base + (int)threadIdx.x;
-        const int v = idx < n ? count[idx] : 0;
-        int total;
-        const int ex = block_exclusive_scan(v, total, s_wave);
-        if (idx < n) start[idx] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) start[n] = carry;
-}
-
-// Step kernel 5: finish the clock of this step (vmax -> next dt, t += dt, stop test) and scan the
-// cell histogram.  Single block.
-__global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Phys ph, int n_vpart,
-                                                           const double *vpart, const int *count,
-                                                           int *start_next, int ncells)
-{
-    if (!clk->run[q]) {
-        if (threadIdx.x == 0) clk->run[1 - q] = 0;
-        return;
-    }
-    double m = 0.0;
-    for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    __shared__ double s_m[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
-        Clock c = *clk;
-        c.vmax = sqrt(m);  // max of sqrt == sqrt of max (monotone, correctly rounded)
-        c.t += c.dt;       // SPH_Poiseuille.m:267
-        c.dt_last = c.dt;
-        c.step += 1;
-        if (c.steps_left > 0) c.steps_left -= 1;
-        if (isinf(m)) c.status = SPHX_ERR_DIVERGED;
-        c.dt = next_dt(c, ph);
-        c.run[1 - q] = loop_continues(c) ? 1 : 0;
-        *clk = c;
-    }
-    scan_counts(count, start_next, ncells);
-}
-
-__global__ __launch_bounds__(kScanBlock) void k_scan_only(const int *count, int *start, int n)
-{
-    scan_counts(count, start, n);
-}
-
-// Step kernel 6: place every particle index into its cell range (arrival order, made canonical by
-// k_reorder).  atomicSub counts the histogram back down to zero, ready for the next step.
-__global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int n, const int *cellid,
-                                                    int *count, const int *start_next, int *perm)
-{
-    if (clk && !clk->run[q]) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int c = cellid[i];
-    const int k = atomicSub(&count[c], 1) - 1;
-    perm[start_next[c] + k] = i;
-}
-
-struct ReorderArgs {
-    int nd;
-    const double *src[8];
-    double *dst[8];
-    const int *id_src;
-    int *id_dst;
-    int *src_of;
-};
-
-// Step kernel 7: canonical rank inside the cell (ascending previous slot -> deterministic order) and
-// the gather of every persistent field into the new ordering.
-__global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int n, const int *cellid,
-                                                    const int *start_next, const int *perm,
-                                                    ReorderArgs a)
-{
-    if (clk && !clk->run[q]) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int c = cellid[i];
-    const int lo = start_next[c], hi = start_next[c + 1];
-    int rank = 0;
-    for (int k = lo; k < hi; ++k) rank += (perm[k] < i) ? 1 : 0;
-    const int dst = lo + rank;
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-        if (f < a.nd) a.dst[f][dst] = a.src[f][i];
-    a.id_dst[dst] = a.id_src[i];
-    if (a.src_of) a.src_of[dst] = i;
-}
-
-__global__ __launch_bounds__(kBlock) void k_iota(int n, int *a, int base)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) a[i] = base + i;
-}
-
-__global__ __launch_bounds__(kBlock) void k_wrap_x(int n, double *x, double DL)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) x[i] = wrap_x(x[i], DL);
-}
-
-__global__ __launch_bounds__(kBlock) void k_wall_volume(int n, const double *mass, double rho0, double *Vol)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) Vol[i] = mass[i] / rho0;  // walls keep rho = rho0 (sph_physics_mex.c:214-216,233)
-}
-
-__global__ void k_row_any(Grid g, const int *wstart, int *row_any)
-{
-    const int cy = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cy >= g.ncy) return;
-    int any = 0;
-    for (int r = max(cy - 1, 0); r <= min(cy + 1, g.ncy - 1) && !any; ++r)
-        for (int cx = 0; cx < g.ncx; ++cx) {
-            const int c = cx * g.ncy + r;
-            if (wstart[c + 1] > wstart[c]) { any = 1; break; }
-        }
-    row_any[cy] = any;
-}
-
-// initial max |v| (vecnorm over the fluid, SPH_Poiseuille.m:521); single block
-__global__ __launch_bounds__(kScanBlock) void k_vmax_init(Clock *clk, int nf, const double *vx, const double *vy)
-{
-    double m = 0.0;
-    for (int k = threadIdx.x; k < nf; k += kScanBlock) {
-        double v2 = vx[k] * vx[k] + vy[k] * vy[k];
-        if (v2 != v2) v2 = INFINITY;
-        m = fmax(m, v2);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    __shared__ double s_m[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
-        clk->vmax = sqrt(m);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// monitors and pair-list emission on the current ordering
-// ---------------------------------------------------------------------------------------------
-
-// wall shear (sph_physics_mex.c:1713-1742): new neighbour structure, new pos/vel, Vol/B of the step
-// that just finished (reached through src_of).  Per-block partial sums, reduced by k_tau_final.
-__global__ __launch_bounds__(kBlock) void k_wall_shear(Grid g, Phys ph, int nf, FluidSet s, FluidTmp t,
-                                                       Walls w, int have_src, double *part /*[2*grid]*/)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    double fb = 0.0, ft = 0.0;
-    if (i < nf) {
-        const double xi = s.x[i], yi = s.y[i];
-        int cx, cy;
-        cell_of(g, xi, yi, cx, cy);
-        if (w.row_any[cy]) {
-            const int o = have_src ? t.src_of[i] : i;
-            const double Voli = t.Vol[o];
-            const double b11 = t.b11[o], b12 = t.b12[o], b21 = t.b21[o], b22 = t.b22[o];
-            const double vxi = s.vx[i];
-            sweep<1>(g, w.start, cx, cy, 0, xi, [&](int k, double xis) {
-                const double dx = xis - w.x[k], dy = yi - w.y[k];
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                    const double r = sqrt(r2);
-                    const double ex = dx / r, ey = dy / r;
-                    const double eBe = ex * (b11 * ex + b12 * ey) + ey * (b21 * ex + b22 * ey);
-                    const double f = 4.0 * ph.mu * eBe * spline_dW(ph.kc, r) * w.Vol[k] * (vxi - w.vx[k]) /
-                                     (r + 0.01 * ph.kc.h) * Voli;
-                    const double yj = w.y[k];
-                    if (yj <= 0.0) fb += f;
-                    else if (yj >= ph.DH) ft += f;
-                }
-            });
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        fb += __shfl_xor(fb, off);
-        ft += __shfl_xor(ft, off);
-    }
-    __shared__ double sb[kBlock / 64], st[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = fb; st[threadIdx.x >> 6] = ft; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < kBlock / 64; ++k) { a += sb[k]; b += st[k]; }
-        part[2 * blockIdx.x] = a;
-        part[2 * blockIdx.x + 1] = b;
-    }
-}
-
-__global__ __launch_bounds__(kScanBlock) void k_tau_final(int nblk, const double *part, double DL, double *out)
-{
-    double a = 0.0, b = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += kScanBlock) { a += part[2 * k]; b += part[2 * k + 1]; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-    __shared__ double sa[kScanBlock / 64], sb[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a = 0.0; b = 0.0;
-        for (int k = 0; k < kScanBlock / 64; ++k) { a += sa[k]; b += sb[k]; }
-        out[0] = -a / DL;
-        out[1] = -b / DL;
-    }
-}
-
-// Pair emission in the MEX convention (sph_neighbor_search_mex.c:353-383): a fluid-fluid pair is
-// produced once, from the particle with the smaller ORIGINAL index; fluid-wall pairs always.
-// mode 0: count into cnt[orig]; mode 1: write at off[orig].
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_pairs(Grid g, Phys ph, int nf, FluidSet s, Walls w, int *cnt,
-                                                  const int *off, double *o_i, double *o_j, double *o_dx,
-                                                  double *o_dy, double *o_r, double *o_W, double *o_dW)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nf) return;
-    const double xi = s.x[i], yi = s.y[i];
-    const int a = s.id[i];
-    int cx, cy;
-    cell_of(g, xi, yi, cx, cy);
-    int n = 0;
-    const int base = MODE ? off[a] : 0;
-    auto emit = [&](int b, double dx, double dy, double r2) {
-        if (MODE) {
-            const double r = sqrt(r2);
-            double W, dW;
-            spline(ph.kc, r, W, dW);
-            const int p = base + n;
-            o_i[p] = (double)(a + 1);
-            o_j[p] = (double)(b + 1);
-            o_dx[p] = dx; o_dy[p] = dy; o_r[p] = r; o_W[p] = W; o_dW[p] = dW;
-        }
-        ++n;
-    };
-    sweep<1>(g, s.start, cx, cy, 0, xi, [&](int k, double xis) {
-        const double dx = xis - s.x[k], dy = yi - s.y[k];
-        const double r2 = dx * dx + dy * dy;
-        if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-            const int b = s.id[k];
-            if (b > a) emit(b, dx, dy, r2);
-        }
-    });
-    if (w.row_any[cy]) {
-        sweep<1>(g, w.start, cx, cy, 0, xi, [&](int k, double xis) {
-            const double dx = xis - w.x[k], dy = yi - w.y[k];
-            const double r2 = dx * dx + dy * dy;
-            if (r2 > kR2Min && r2 < ph.kc.rcut2) emit(w.id[k], dx, dy, r2);
-        });
-    }
-    if (!MODE) cnt[a] = n;
-}
-
-// scatter a sorted field back to the caller's row numbering
-__global__ __launch_bounds__(kBlock) void k_unsort(int n, const int *id, const double *src, double *dst)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) dst[id[i]] = src[i];
-}
-
-__global__ __launch_bounds__(kBlock) void k_fill(int n, double *dst, double v)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) dst[i] = v;
-}
-
-}  // namespace
-
-// ---------------------------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------------------------
 struct KernelTimer {
     std::vector<std::string> names;
     std::vector<double> total_ms;
     std::vector<int64_t> launches;
     struct Pending { int idx; hipEvent_t a, b; };
-    std::vector<Pending> pending;
+    std::vector<Pending> pending;     // eager launches: one-shot events
+    std::vector<Pending> graph_evs;   // events recorded by nodes of the profiling graph (re-armed per replay)
     int index_of(const char *name)
     {
         for (size_t k = 0; k < names.size(); ++k) if (names[k] == name) return (int)k;
         names.emplace_back(name); total_ms.push_back(0.0); launches.push_back(0);
         return (int)names.size() - 1;
     }
+    void add(int idx, hipEvent_t a, hipEvent_t b)
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess) { total_ms[idx] += ms; launches[idx] += 1; }
+        else (void)hipGetLastError();
+    }
     void collect()
     {
-        for (auto &p : pending) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { total_ms[p.idx] += ms; launches[p.idx] += 1; }
-            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
-        }
+        for (auto &p : pending) { add(p.idx, p.a, p.b); (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         pending.clear();
+    }
+    void collect_graph() { for (auto &p : graph_evs) add(p.idx, p.a, p.b); }
+    void drop_graph_events()
+    {
+        for (auto &p : graph_evs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        graph_evs.clear();
     }
 };
 
@@ -800,19 +51,22 @@ struct sphx_ctx {
     sphx_params prm{};
     Grid grid{};
     Phys phys{};
-    int nf = 0, nw = 0, nt = 0;
-    int lpp = 1;
-    int spg = 2;
-    int cur = 0;  // which FluidSet holds the current state
+    int nf = 0, nw = 0, nt = 0;  // caller's global counts (single GPU: nf particles resident)
+    int cap = 0;                 // particle capacity of the device arrays
+    int lpp = 1, spg = 2;
+    int cur = 0;                 // which FluidSet holds the current state
     int64_t step_at_cur0 = 0;
     bool have_step_outputs = false;
+    bool big_scan = false;
+    int n_tiles = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
 
     // storage
     DevBuf<double> fx_[2], fy_[2], fvx_[2], fvy_[2], fdrho_[2], fmass_[2];
     DevBuf<int> fid_[2], fstart_[2];
     DevBuf<double> xn, yn, vxn, vyn, drhon, rho, Vol, rhoh, ph, b11, b12, b21, b22, fpx, fpy, ffx, ffy, rho_out, p_out, vpart;
-    DevBuf<int> cellid, count, perm, src_of;
+    DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, flags, tile;
     DevBuf<double> wx, wy, wVol, wvx, wvy;
     DevBuf<int> wid, wstart, wrow_any;
     DevBuf<Clock> clock;
@@ -822,11 +76,16 @@ struct sphx_ctx {
     FluidSet set[2]{};
     FluidTmp tmp{};
     Walls walls{};
-    int n_blocks_particles = 0;  // grid of the LPP kernels
+    int n_blocks_particles = 0;  // grid of the LPP kernels (capacity based)
+    int n_blocks_flat = 0;       // grid of one-thread-per-particle kernels
 
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t pgraph = nullptr;       // profiling graph: same steps with event-record nodes
+    hipGraphExec_t pgraph_exec = nullptr;
+    bool pgraph_failed = false;
     bool profiling = false;
+    bool capturing_profile = false;
     KernelTimer timer;
 
     // pair list held for sphx_neighbor_fetch
@@ -834,21 +93,37 @@ struct sphx_ctx {
     size_t pl_n = 0;
     bool pl_valid = false;
 
+    // x-slab state
+    bool is_slab = false;
+    int rank = 0, n_ranks = 1, halo_cols = 0, msg_cap = 0;
+    int col0 = 0, col1 = 0;  // owned global columns [col0, col1)
+    DevBuf<double> kx, ky, kvx, kvy, kdrho, kmass;
+    DevBuf<int> kid, counters, n_new;
+    SlabPack pack{};
+    int64_t slab_steps_enqueued = 0;
+
     ~sphx_ctx()
     {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (graph) (void)hipGraphDestroy(graph);
+        if (pgraph_exec) (void)hipGraphExecDestroy(pgraph_exec);
+        if (pgraph) (void)hipGraphDestroy(pgraph);
+        timer.collect();
+        timer.drop_graph_events();
         if (h_clock) (void)hipHostFree(h_clock);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
 };
 
 namespace {
 
+thread_local sphx_ctx *g_search_ctx = nullptr;  // owns the temporary context of sphx_neighbor_search until fetch
+thread_local sphx_ctx *g_fetch_src = nullptr;   // context whose pair list the next sphx_neighbor_fetch copies out
+
 template <typename K, typename... Args>
 void launch(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, Args... args)
 {
-    if (c->profiling) {
+    if (c->profiling || c->capturing_profile) {
         KernelTimer::Pending p;
         p.idx = c->timer.index_of(name);
         SPHX_HIP(hipEventCreate(&p.a));
@@ -856,52 +131,115 @@ void launch(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, Args
         SPHX_HIP(hipEventRecord(p.a, c->stream));
         hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, args...);
         SPHX_HIP(hipEventRecord(p.b, c->stream));
-        c->timer.pending.push_back(p);
+        (c->capturing_profile ? c->timer.graph_evs : c->timer.pending).push_back(p);
     } else {
         hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, args...);
     }
 }
 
+ReorderArgs reorder_args(const double *const src[6], const int *id_src, const FluidSet &d, int *src_of)
+{
+    ReorderArgs ra{};
+    ra.nd = 6;
+    double *dst[6] = {d.x, d.y, d.vx, d.vy, d.drho, d.mass};
+    for (int f = 0; f < 6; ++f) { ra.src[f] = src[f]; ra.dst[f] = dst[f]; }
+    ra.id_src = id_src;
+    ra.id_dst = d.id;
+    ra.src_of = src_of;
+    return ra;
+}
+
 template <int LPP>
-void launch_step_lpp(sphx_ctx *c, int q)
+void launch_physics(sphx_ctx *c, int q, int do_hist)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
-    const dim3 g1(div_up(c->nf, kBlock));
+    const Clock *clk = c->clock.get();
+    const FluidSet &s = c->set[q];
+    launch(c, "k_density", k_density<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
+    launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
+    launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
+    launch(c, "k_continuity", k_continuity<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls, do_hist);
+}
+
+void launch_physics_any(sphx_ctx *c, int q, int do_hist)
+{
+    switch (c->lpp) {
+        case 1: launch_physics<1>(c, q, do_hist); break;
+        case 2: launch_physics<2>(c, q, do_hist); break;
+        case 4: launch_physics<4>(c, q, do_hist); break;
+        case 8: launch_physics<8>(c, q, do_hist); break;
+        case 16: launch_physics<16>(c, q, do_hist); break;
+        case 32: launch_physics<32>(c, q, do_hist); break;
+        default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
+    }
+}
+
+// exclusive scan of the cell histogram into start_next (three kernels on big grids)
+void launch_cell_scan(sphx_ctx *c, int q, int *start_next)
+{
+    const Clock *clk = c->clock.get();
+    if (!c->big_scan) {
+        launch(c, "k_scan", k_scan_only, dim3(1), dim3(kScanBlock), clk, q, (const int *)c->count.get(), start_next,
+               c->grid.ncells);
+    } else {
+        int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
+        launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), clk, q, (const int *)c->count.get(),
+               start_next, tile_sum, c->grid.ncells);
+        launch(c, "k_scan_sums", k_scan_only, dim3(1), dim3(kScanBlock), clk, q, (const int *)tile_sum, tile_off, c->n_tiles);
+        launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), clk, q, start_next, (const int *)tile_off,
+               c->grid.ncells, c->n_tiles);
+    }
+}
+
+void launch_scatter_reorder(sphx_ctx *c, int q, const double *const src[6], const int *id_src, int *src_of)
+{
+    const Clock *clk = c->clock.get();
+    const FluidSet &d = c->set[1 - q];
+    const dim3 g1(c->n_blocks_flat), bp(kBlock);
+    launch(c, "k_scatter", k_scatter, g1, bp, clk, q, 0, (const int *)c->cellid.get(), c->count.get(), (const int *)d.start,
+           c->perm.get());
+    launch(c, "k_reorder", k_reorder, g1, bp, clk, q, 0, (const int *)c->cellid.get(), (const int *)d.start,
+           (const int *)c->perm.get(), reorder_args(src, id_src, d, src_of));
+}
+
+// one single-GPU step slot of parity q
+void launch_step(sphx_ctx *c, int q)
+{
+    launch_physics_any(c, q, 1);
     Clock *clk = c->clock.get();
     const FluidSet &s = c->set[q];
     const FluidSet &d = c->set[1 - q];
-    launch(c, "k_density", k_density<LPP>, gp, bp, (const Clock *)clk, q, c->grid, c->phys, c->nf, s, c->tmp, c->walls);
-    launch(c, "k_kgc", k_kgc<LPP>, gp, bp, (const Clock *)clk, q, c->grid, c->phys, c->nf, s, c->tmp, c->walls);
-    launch(c, "k_forces", k_forces<LPP>, gp, bp, (const Clock *)clk, q, c->grid, c->phys, c->nf, s, c->tmp, c->walls);
-    launch(c, "k_continuity", k_continuity<LPP>, gp, bp, (const Clock *)clk, q, c->grid, c->phys, c->nf, s, c->tmp, c->walls);
-    launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_blocks_particles,
-           (const double *)c->vpart.get(), (const int *)c->count.get(), d.start, c->grid.ncells);
-    launch(c, "k_scatter", k_scatter, g1, bp, (const Clock *)clk, q, c->nf, (const int *)c->cellid.get(), c->count.get(),
-           (const int *)d.start, c->perm.get());
-    ReorderArgs ra{};
-    ra.nd = 6;
-    ra.src[0] = c->tmp.xn; ra.dst[0] = d.x;
-    ra.src[1] = c->tmp.yn; ra.dst[1] = d.y;
-    ra.src[2] = c->tmp.vxn; ra.dst[2] = d.vx;
-    ra.src[3] = c->tmp.vyn; ra.dst[3] = d.vy;
-    ra.src[4] = c->tmp.drhon; ra.dst[4] = d.drho;
-    ra.src[5] = s.mass; ra.dst[5] = d.mass;
-    ra.id_src = s.id; ra.id_dst = d.id; ra.src_of = c->tmp.src_of;
-    launch(c, "k_reorder", k_reorder, g1, bp, (const Clock *)clk, q, c->nf, (const int *)c->cellid.get(),
-           (const int *)d.start, (const int *)c->perm.get(), ra);
+    if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_blocks_particles,
+               (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(),
+               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr);
+    } else {
+        int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
+        launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
+               (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_blocks_particles,
+               (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(), (const int *)tile_sum,
+               tile_off, c->n_tiles, (const int *)nullptr);
+        launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
+               (const int *)tile_off, c->grid.ncells, c->n_tiles);
+    }
+    const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
+    launch_scatter_reorder(c, q, src, s.id, c->tmp.src_of);
 }
 
-void launch_step(sphx_ctx *c, int q)
+void capture_steps(sphx_ctx *c, hipGraph_t *g, hipGraphExec_t *e)
 {
-    switch (c->lpp) {
-        case 1: launch_step_lpp<1>(c, q); break;
-        case 2: launch_step_lpp<2>(c, q); break;
-        case 4: launch_step_lpp<4>(c, q); break;
-        case 8: launch_step_lpp<8>(c, q); break;
-        case 16: launch_step_lpp<16>(c, q); break;
-        case 32: launch_step_lpp<32>(c, q); break;
-        default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
+    SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    try {
+        for (int k = 0; k < c->spg; ++k) launch_step(c, k & 1);
+    } catch (...) {
+        hipGraph_t junk = nullptr;
+        (void)hipStreamEndCapture(c->stream, &junk);
+        if (junk) (void)hipGraphDestroy(junk);
+        throw;
     }
+    SPHX_HIP(hipStreamEndCapture(c->stream, g));
+    SPHX_HIP(hipGraphInstantiate(e, *g, nullptr, nullptr, 0));
 }
 
 void build_graph(sphx_ctx *c)
@@ -909,11 +247,29 @@ void build_graph(sphx_ctx *c)
     if (c->graph_exec) return;
     const bool prof = c->profiling;
     c->profiling = false;
-    SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    for (int k = 0; k < c->spg; ++k) launch_step(c, k & 1);
-    SPHX_HIP(hipStreamEndCapture(c->stream, &c->graph));
-    SPHX_HIP(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+    try { capture_steps(c, &c->graph, &c->graph_exec); } catch (...) { c->profiling = prof; throw; }
     c->profiling = prof;
+}
+
+// profiling graph: the same step slots with an event-record node on either side of every kernel, so the
+// per-kernel device time is measured in the regime the timed region runs in (graph replay)
+bool build_profile_graph(sphx_ctx *c)
+{
+    if (c->pgraph_exec) return true;
+    if (c->pgraph_failed) return false;
+    const bool prof = c->profiling;
+    c->profiling = false;
+    c->capturing_profile = true;
+    try {
+        capture_steps(c, &c->pgraph, &c->pgraph_exec);
+    } catch (const std::exception &) {
+        (void)hipGetLastError();
+        c->timer.drop_graph_events();
+        c->pgraph_failed = true;
+    }
+    c->capturing_profile = false;
+    c->profiling = prof;
+    return !c->pgraph_failed;
 }
 
 // enqueue `slots` step slots starting at parity c->cur (slots that find run[q]==0 are no-ops)
@@ -922,7 +278,14 @@ void enqueue_slots(sphx_ctx *c, int64_t slots)
     int q = c->cur;
     int64_t left = slots;
     if (left > 0 && q == 1) { launch_step(c, 1); q = 0; --left; }
-    if (!c->profiling && left >= c->spg) {
+    if (c->profiling && left >= c->spg && build_profile_graph(c)) {
+        while (left >= c->spg) {
+            SPHX_HIP(hipGraphLaunch(c->pgraph_exec, c->stream));
+            SPHX_HIP(hipStreamSynchronize(c->stream));
+            c->timer.collect_graph();
+            left -= c->spg;
+        }
+    } else if (!c->profiling && left >= c->spg) {
         build_graph(c);
         while (left >= c->spg) { SPHX_HIP(hipGraphLaunch(c->graph_exec, c->stream)); left -= c->spg; }
     }
@@ -934,11 +297,10 @@ void read_clock(sphx_ctx *c)
 {
     SPHX_HIP(hipMemcpyAsync(c->h_clock, c->clock.get(), sizeof(Clock), hipMemcpyDeviceToHost, c->stream));
     SPHX_HIP(hipStreamSynchronize(c->stream));
-    if (c->profiling) c->timer.collect();
+    c->timer.collect();
     const int64_t executed = (int64_t)c->h_clock->step - c->step_at_cur0;
-    const int new_cur = (int)(executed & 1);
     if (executed > 0) c->have_step_outputs = true;
-    c->cur = new_cur;
+    c->cur = (int)(executed & 1);
 }
 
 void fill_status(sphx_ctx *c, sphx_status *st)
@@ -956,37 +318,177 @@ void fill_status(sphx_ctx *c, sphx_status *st)
 
 int pick_lpp(int nf)
 {
-    // enough lanes to put ~2 waves on each of the 1024 SIMDs, never more than 16 lanes per particle
+    // enough lanes to put ~2 waves on each of the 1024 SIMDs, never more than 32 lanes per particle
     const long target = 256L * 4 * 2 * 64;
     int lpp = 1;
-    while (lpp < 16 && (long)nf * lpp * 2 <= target) lpp *= 2;
+    while (lpp < 32 && (long)nf * lpp * 2 <= target) lpp *= 2;
     return lpp;
 }
 
-// sort `n` particles given in arbitrary order (x,y in tx,ty) into cell order; generic over the field list
-void initial_sort(sphx_ctx *c, int n, const double *x, const double *y, int *cellid, int *count, int *start,
-                  int *perm, const ReorderArgs &ra)
+int nl_cap_for(int lpp) { return std::max(64 / lpp, 16); }
+
+// sort `n` particles given in arbitrary order into cell order on the device (context creation)
+void initial_sort(sphx_ctx *c, const Grid &g, int n, const double *x, const double *y, int *cellid, int *count,
+                  int *start, int *perm, const ReorderArgs &ra)
 {
+    hipStream_t s = c->stream;
     if (n <= 0) {
-        SPHX_HIP(hipMemsetAsync(start, 0, ((size_t)c->grid.ncells + 1) * sizeof(int), c->stream));
+        SPHX_HIP(hipMemsetAsync(start, 0, ((size_t)g.ncells + 1) * sizeof(int), s));
         return;
     }
-    hipLaunchKernelGGL(k_bin, dim3(div_up(n, kBlock)), dim3(kBlock), 0, c->stream, c->grid, n, x, y, cellid, count);
-    hipLaunchKernelGGL(k_scan_only, dim3(1), dim3(kScanBlock), 0, c->stream, (const int *)count, start, c->grid.ncells);
-    hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, c->stream, (const Clock *)nullptr, 0, n,
+    hipLaunchKernelGGL(k_bin, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, g, n, x, y, cellid, count);
+    hipLaunchKernelGGL(k_scan_only, dim3(1), dim3(kScanBlock), 0, s, (const Clock *)nullptr, 0, (const int *)count, start, g.ncells);
+    hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
                        (const int *)cellid, count, (const int *)start, perm);
-    hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, c->stream, (const Clock *)nullptr, 0, n,
+    hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
                        (const int *)cellid, (const int *)start, (const int *)perm, ra);
     SPHX_HIP(hipGetLastError());
 }
 
-void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, const double *pos, const double *vel,
-               const double *drho_dt, const double *mass, const double *wall_vel, double t0, int64_t step0)
+Phys make_phys(const sphx_params *prm)
+{
+    Phys ph{};
+    ph.kc = make_kernel_const(prm->h);
+    ph.rho0 = prm->rho0; ph.inv_sigma0 = prm->inv_sigma0; ph.mu = prm->mu; ph.p0 = prm->p0; ph.c_f = prm->c_f;
+    ph.g = prm->gravity_g; ph.tc = prm->transport_coeff; ph.nu = prm->mu / prm->rho0; ph.DL = prm->DL; ph.DH = prm->DH;
+    ph.w0 = ph.kc.sigma;
+    return ph;
+}
+
+// allocate every device array for `cap` particles and the grid of the context
+void ctx_alloc(sphx_ctx *c, int cap)
+{
+    const Grid &g = c->grid;
+    c->cap = cap;
+    c->n_blocks_particles = (int)div_up((size_t)cap * c->lpp, kBlock);
+    c->n_blocks_flat = (int)div_up((size_t)cap, kBlock);
+    for (int k = 0; k < 2; ++k) {
+        c->fx_[k].alloc(cap); c->fy_[k].alloc(cap); c->fvx_[k].alloc(cap); c->fvy_[k].alloc(cap);
+        c->fdrho_[k].alloc(cap); c->fmass_[k].alloc(cap); c->fid_[k].alloc(cap);
+        c->fstart_[k].alloc((size_t)g.ncells + 1);
+        c->set[k] = FluidSet{c->fx_[k].get(), c->fy_[k].get(), c->fvx_[k].get(), c->fvy_[k].get(), c->fdrho_[k].get(),
+                             c->fmass_[k].get(), c->fid_[k].get(), c->fstart_[k].get()};
+    }
+    DevBuf<double> *dbl[] = {&c->xn, &c->yn, &c->vxn, &c->vyn, &c->drhon, &c->rho, &c->Vol, &c->rhoh, &c->ph, &c->b11,
+                             &c->b12, &c->b21, &c->b22, &c->fpx, &c->fpy, &c->ffx, &c->ffy, &c->rho_out, &c->p_out};
+    for (auto *b : dbl) { b->alloc(cap); b->zero(c->stream); }
+    c->vpart.alloc(c->n_blocks_particles);
+    c->vpart.zero(c->stream);
+    c->cellid.alloc(cap); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(cap); c->src_of.alloc(cap);
+    c->count.zero(c->stream);
+    const int nl_cap = nl_cap_for(c->lpp);
+    const size_t stride = (size_t)c->n_blocks_particles * kBlock;  // one list column per launched lane
+    c->nl_idx.alloc(stride * nl_cap);
+    c->nl_cnt.alloc(stride);
+    c->nl_cnt.zero(c->stream);
+    c->flags.alloc(1);
+    c->flags.zero(c->stream);
+    c->big_scan = g.ncells > kBigScanCells;
+    c->n_tiles = (int)div_up((size_t)g.ncells, kScanBlock);
+    c->tile.alloc(2 * ((size_t)c->n_tiles + 1));
+    c->tmp = FluidTmp{c->xn.get(), c->yn.get(), c->vxn.get(), c->vyn.get(), c->drhon.get(), c->rho.get(), c->Vol.get(),
+                      c->rhoh.get(), c->ph.get(), c->b11.get(), c->b12.get(), c->b21.get(), c->b22.get(), c->fpx.get(),
+                      c->fpy.get(), c->ffx.get(), c->ffy.get(), c->rho_out.get(), c->p_out.get(), c->cellid.get(),
+                      c->count.get(), c->perm.get(), c->src_of.get(), c->vpart.get(), c->nl_idx.get(), c->nl_cnt.get(),
+                      c->flags.get(), c->tile.get(), (int)stride, nl_cap};
+    c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
+    c->tau_out.alloc(2);
+}
+
+// upload n fluid particles (host SoA) and sort them into set[0]
+void upload_fluid(sphx_ctx *c, int n, const double *hx, const double *hy, const double *hvx, const double *hvy,
+                  const double *hdrho, const double *hmass, const int *hid, bool wrap)
+{
+    hipStream_t s = c->stream;
+    if (n > 0) {
+        c->xn.upload(hx, n, s); c->yn.upload(hy, n, s); c->vxn.upload(hvx, n, s); c->vyn.upload(hvy, n, s);
+        c->drhon.upload(hdrho, n, s);
+        c->fmass_[1].upload(hmass, n, s);
+        if (hid) c->fid_[1].upload(hid, n, s);
+        else hipLaunchKernelGGL(k_iota, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, c->fid_[1].get(), 0);
+        if (wrap) hipLaunchKernelGGL(k_wrap_x, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, c->xn.get(), c->prm.DL);
+    }
+    const double *src[6] = {c->xn.get(), c->yn.get(), c->vxn.get(), c->vyn.get(), c->drhon.get(), c->fmass_[1].get()};
+    initial_sort(c, c->grid, n, c->xn.get(), c->yn.get(), c->cellid.get(), c->count.get(), c->set[0].start, c->perm.get(),
+                 reorder_args(src, c->fid_[1].get(), c->set[0], nullptr));
+    SPHX_HIP(hipStreamSynchronize(s));  // host staging vectors of the caller may die after this
+}
+
+// upload nw wall particles (host SoA, x already in this context's frame) and sort them once
+void upload_walls(sphx_ctx *c, int nw, const double *hx, const double *hy, const double *hmass, const double *hvx,
+                  const double *hvy, const int *hid, bool wrap)
+{
+    const Grid &g = c->grid;
+    hipStream_t s = c->stream;
+    const size_t nwz = nw > 0 ? (size_t)nw : 1;
+    c->wx.alloc(nwz); c->wy.alloc(nwz); c->wVol.alloc(nwz); c->wvx.alloc(nwz); c->wvy.alloc(nwz); c->wid.alloc(nwz);
+    c->wstart.alloc((size_t)g.ncells + 1); c->wrow_any.alloc(g.ncy);
+    DevBuf<double> tx(nwz), ty(nwz), tm(nwz), tV(nwz), tvx(nwz), tvy(nwz);
+    DevBuf<int> tid(nwz), tcell(nwz), tperm(nwz), tcount((size_t)g.ncells + 1);
+    tcount.zero(s);
+    if (nw > 0) {
+        tx.upload(hx, nw, s); ty.upload(hy, nw, s); tm.upload(hmass, nw, s); tvx.upload(hvx, nw, s); tvy.upload(hvy, nw, s);
+        tid.upload(hid, nw, s);
+        if (wrap) hipLaunchKernelGGL(k_wrap_x, dim3(div_up(nw, kBlock)), dim3(kBlock), 0, s, nw, tx.get(), c->prm.DL);
+        hipLaunchKernelGGL(k_wall_volume, dim3(div_up(nw, kBlock)), dim3(kBlock), 0, s, nw, (const double *)tm.get(),
+                           c->prm.rho0, tV.get());
+    }
+    ReorderArgs ra{};
+    ra.nd = 5;
+    const double *src[5] = {tx.get(), ty.get(), tV.get(), tvx.get(), tvy.get()};
+    double *dst[5] = {c->wx.get(), c->wy.get(), c->wVol.get(), c->wvx.get(), c->wvy.get()};
+    for (int f = 0; f < 5; ++f) { ra.src[f] = src[f]; ra.dst[f] = dst[f]; }
+    ra.id_src = tid.get(); ra.id_dst = c->wid.get(); ra.src_of = nullptr;
+    initial_sort(c, g, nw, tx.get(), ty.get(), tcell.get(), tcount.get(), c->wstart.get(), tperm.get(), ra);
+    hipLaunchKernelGGL(k_row_any, dim3(div_up(g.ncy, 64)), dim3(64), 0, s, g, (const int *)c->wstart.get(), c->wrow_any.get());
+    SPHX_HIP(hipGetLastError());
+    SPHX_HIP(hipStreamSynchronize(s));  // temporaries die here
+    c->walls = Walls{c->wx.get(), c->wy.get(), c->wVol.get(), c->wvx.get(), c->wvy.get(), c->wid.get(),
+                     c->wstart.get(), c->wrow_any.get(), nw};
+}
+
+void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
+{
+    hipStream_t s = c->stream;
+    c->clock.alloc(1);
+    Clock k{};
+    k.t = t0; k.dt = 0.0; k.dt_last = 0.0; k.t_target = t0; k.t_end = c->prm.t_end; k.vmax = 0.0;
+    k.step = step0; k.steps_left = -1; k.run[0] = 0; k.run[1] = 0; k.status = 0; k.n = n;
+    *c->h_clock = k;
+    SPHX_HIP(hipMemcpyAsync(c->clock.get(), c->h_clock, sizeof(Clock), hipMemcpyHostToDevice, s));
+    SPHX_HIP(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, s, c->clock.get(), c->grid, (const double *)c->set[0].x,
+                       (const double *)c->set[0].vx, (const double *)c->set[0].vy, (double *)nullptr);
+    SPHX_HIP(hipGetLastError());
+    c->cur = 0;
+    c->step_at_cur0 = step0;
+}
+
+void common_checks(const sphx_params *prm, int n_fluid, int n_total)
 {
     require(prm != nullptr, "SPHX:Ctx:params", "params must not be NULL");
     require(n_total > 0 && n_fluid > 0 && n_fluid <= n_total, "SPH:Neighbor:count",
             "Invalid n_fluid/n_total or inconsistent pos size.");
     require(prm->h > 0.0 && prm->DL > 0.0, "SPH:Neighbor:param", "h and DL must be positive.");
+}
+
+void y_extent(const double *py, int n_total, double &y_min, double &y_max)
+{
+    y_min = py[0]; y_max = py[0];
+    for (int i = 1; i < n_total; ++i) { y_min = std::min(y_min, py[i]); y_max = std::max(y_max, py[i]); }
+    require(std::isfinite(y_min) && std::isfinite(y_max), "SPH:Neighbor:pos", "pos must be finite.");
+}
+
+void check_lpp(int lpp)
+{
+    require(lpp == 1 || lpp == 2 || lpp == 4 || lpp == 8 || lpp == 16 || lpp == 32, "SPHX:Ctx:lpp",
+            "lanes_per_particle must be 1,2,4,8,16 or 32");
+}
+
+void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, const double *pos, const double *vel,
+               const double *drho_dt, const double *mass, const double *wall_vel, double t0, int64_t step0)
+{
+    common_checks(prm, n_fluid, n_total);
     ensure_device();
     c->prm = *prm;
     c->nf = n_fluid;
@@ -997,9 +499,8 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     const double *px = pos, *py = pos + ntz;
 
     // grid: exact periodic tiling in x (cells >= 2h), 2h rows in y over fluid + wall extent
-    double y_min = py[0], y_max = py[0];
-    for (int i = 1; i < n_total; ++i) { y_min = std::min(y_min, py[i]); y_max = std::max(y_max, py[i]); }
-    require(std::isfinite(y_min) && std::isfinite(y_max), "SPH:Neighbor:pos", "pos must be finite.");
+    double y_min, y_max;
+    y_extent(py, n_total, y_min, y_max);
     const double cs = 2.0 * prm->h;
     Grid g{};
     g.ncx = (int)std::floor(prm->DL / cs);
@@ -1007,141 +508,75 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     g.ncy = (int)std::ceil((y_max - y_min + 1e-12) / cs) + 1;
     require((double)g.ncx * (double)g.ncy < 2.0e9, "SPH:Neighbor:param", "cell grid too large.");
     g.ncells = g.ncx * g.ncy;
+    g.periodic = 1;
     g.DL = prm->DL;
+    g.half_DL = 0.5 * prm->DL;
+    g.x0 = 0.0;
     g.y0 = y_min;
     g.inv_csx = (double)g.ncx / prm->DL;
     g.inv_csy = 1.0 / cs;
+    g.own_lo = -std::numeric_limits<double>::infinity();
+    g.own_hi = std::numeric_limits<double>::infinity();
     c->grid = g;
-
-    Phys ph{};
-    ph.kc = make_kernel_const(prm->h);
-    ph.rho0 = prm->rho0; ph.inv_sigma0 = prm->inv_sigma0; ph.mu = prm->mu; ph.p0 = prm->p0; ph.c_f = prm->c_f;
-    ph.g = prm->gravity_g; ph.tc = prm->transport_coeff; ph.nu = prm->mu / prm->rho0; ph.DL = prm->DL; ph.DH = prm->DH;
-    ph.w0 = ph.kc.sigma;
-    c->phys = ph;
+    c->phys = make_phys(prm);
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
-    require(c->lpp == 1 || c->lpp == 2 || c->lpp == 4 || c->lpp == 8 || c->lpp == 16 || c->lpp == 32, "SPHX:Ctx:lpp",
-            "lanes_per_particle must be 1,2,4,8,16 or 32");
+    check_lpp(c->lpp);
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 16;
     if (c->spg & 1) c->spg += 1;
-    c->n_blocks_particles = (int)div_up((size_t)nf * c->lpp, kBlock);
 
     SPHX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     SPHX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_clock), sizeof(Clock), hipHostMallocDefault));
-
-    for (int k = 0; k < 2; ++k) {
-        c->fx_[k].alloc(nf); c->fy_[k].alloc(nf); c->fvx_[k].alloc(nf); c->fvy_[k].alloc(nf);
-        c->fdrho_[k].alloc(nf); c->fmass_[k].alloc(nf); c->fid_[k].alloc(nf);
-        c->fstart_[k].alloc((size_t)g.ncells + 1);
-        c->set[k] = FluidSet{c->fx_[k].get(), c->fy_[k].get(), c->fvx_[k].get(), c->fvy_[k].get(), c->fdrho_[k].get(),
-                             c->fmass_[k].get(), c->fid_[k].get(), c->fstart_[k].get()};
-    }
-    DevBuf<double> *dbl[] = {&c->xn, &c->yn, &c->vxn, &c->vyn, &c->drhon, &c->rho, &c->Vol, &c->rhoh, &c->ph, &c->b11,
-                             &c->b12, &c->b21, &c->b22, &c->fpx, &c->fpy, &c->ffx, &c->ffy, &c->rho_out, &c->p_out};
-    for (auto *b : dbl) { b->alloc(nf); b->zero(c->stream); }
-    c->vpart.alloc(c->n_blocks_particles);
-    c->cellid.alloc(nf); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(nf); c->src_of.alloc(nf);
-    c->count.zero(c->stream);
-    c->tmp = FluidTmp{c->xn.get(), c->yn.get(), c->vxn.get(), c->vyn.get(), c->drhon.get(), c->rho.get(), c->Vol.get(),
-                      c->rhoh.get(), c->ph.get(), c->b11.get(), c->b12.get(), c->b21.get(), c->b22.get(), c->fpx.get(),
-                      c->fpy.get(), c->ffx.get(), c->ffy.get(), c->rho_out.get(), c->p_out.get(), c->cellid.get(),
-                      c->count.get(), c->perm.get(), c->src_of.get(), c->vpart.get()};
-
-    // ---- fluid: upload in caller order into the "temp" arrays, wrap x, sort into set[0]
-    hipStream_t s = c->stream;
-    c->xn.upload(px, nf, s); c->yn.upload(py, nf, s);
-    c->vxn.upload(vel, nf, s); c->vyn.upload(vel + ntz, nf, s);
-    c->drhon.upload(drho_dt, nf, s);
-    c->fmass_[1].upload(mass, nf, s);
-    hipLaunchKernelGGL(k_iota, dim3(div_up(nf, kBlock)), dim3(kBlock), 0, s, nf, c->fid_[1].get(), 0);
-    hipLaunchKernelGGL(k_wrap_x, dim3(div_up(nf, kBlock)), dim3(kBlock), 0, s, nf, c->xn.get(), prm->DL);
-    {
-        ReorderArgs ra{};
-        ra.nd = 6;
-        const double *src[6] = {c->xn.get(), c->yn.get(), c->vxn.get(), c->vyn.get(), c->drhon.get(), c->fmass_[1].get()};
-        double *dst[6] = {c->set[0].x, c->set[0].y, c->set[0].vx, c->set[0].vy, c->set[0].drho, c->set[0].mass};
-        for (int f = 0; f < 6; ++f) { ra.src[f] = src[f]; ra.dst[f] = dst[f]; }
-        ra.id_src = c->fid_[1].get(); ra.id_dst = c->set[0].id; ra.src_of = nullptr;
-        initial_sort(c, nf, c->xn.get(), c->yn.get(), c->cellid.get(), c->count.get(), c->set[0].start, c->perm.get(), ra);
-    }
-
-    // ---- walls: static, sorted once on the same grid
-    const size_t nwz = nw > 0 ? (size_t)nw : 1;
-    c->wx.alloc(nwz); c->wy.alloc(nwz); c->wVol.alloc(nwz); c->wvx.alloc(nwz); c->wvy.alloc(nwz); c->wid.alloc(nwz);
-    c->wstart.alloc((size_t)g.ncells + 1); c->wrow_any.alloc(g.ncy);
-    {
-        DevBuf<double> tx(nwz), ty(nwz), tm(nwz), tV(nwz), tvx(nwz), tvy(nwz);
-        DevBuf<int> tid(nwz), tcell(nwz), tperm(nwz), tcount((size_t)g.ncells + 1);
-        tcount.zero(s);
-        if (nw > 0) {
-            tx.upload(px + nf, nw, s); ty.upload(py + nf, nw, s); tm.upload(mass + nf, nw, s);
-            tvx.upload(wall_vel + nf, nw, s); tvy.upload(wall_vel + ntz + nf, nw, s);
-            hipLaunchKernelGGL(k_iota, dim3(div_up(nw, kBlock)), dim3(kBlock), 0, s, nw, tid.get(), nf);
-            hipLaunchKernelGGL(k_wrap_x, dim3(div_up(nw, kBlock)), dim3(kBlock), 0, s, nw, tx.get(), prm->DL);
-            hipLaunchKernelGGL(k_wall_volume, dim3(div_up(nw, kBlock)), dim3(kBlock), 0, s, nw, (const double *)tm.get(),
-                               prm->rho0, tV.get());
-        }
-        ReorderArgs ra{};
-        ra.nd = 5;
-        const double *src[5] = {tx.get(), ty.get(), tV.get(), tvx.get(), tvy.get()};
-        double *dst[5] = {c->wx.get(), c->wy.get(), c->wVol.get(), c->wvx.get(), c->wvy.get()};
-        for (int f = 0; f < 5; ++f) { ra.src[f] = src[f]; ra.dst[f] = dst[f]; }
-        ra.id_src = tid.get(); ra.id_dst = c->wid.get(); ra.src_of = nullptr;
-        initial_sort(c, nw, tx.get(), ty.get(), tcell.get(), tcount.get(), c->wstart.get(), tperm.get(), ra);
-        hipLaunchKernelGGL(k_row_any, dim3(div_up(g.ncy, 64)), dim3(64), 0, s, g, (const int *)c->wstart.get(),
-                           c->wrow_any.get());
-        SPHX_HIP(hipGetLastError());
-        SPHX_HIP(hipStreamSynchronize(s));  // temporaries die here
-    }
-    c->walls = Walls{c->wx.get(), c->wy.get(), c->wVol.get(), c->wvx.get(), c->wvy.get(), c->wid.get(),
-                     c->wstart.get(), c->wrow_any.get(), nw};
-
-    // ---- clock
-    c->clock.alloc(1);
-    Clock k{};
-    k.t = t0; k.dt = 0.0; k.dt_last = 0.0; k.t_target = t0; k.t_end = prm->t_end; k.vmax = 0.0;
-    k.step = step0; k.steps_left = -1; k.run[0] = 0; k.run[1] = 0; k.status = 0;
-    *c->h_clock = k;
-    SPHX_HIP(hipMemcpyAsync(c->clock.get(), c->h_clock, sizeof(Clock), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, s, c->clock.get(), nf, (const double *)c->set[0].vx,
-                       (const double *)c->set[0].vy);
-    SPHX_HIP(hipGetLastError());
-    c->cur = 0;
-    c->step_at_cur0 = step0;
-    const int nblk = (int)div_up(nf, kBlock);
-    c->tau_part.alloc((size_t)2 * nblk);
-    c->tau_out.alloc(2);
+    ctx_alloc(c, nf);
+    upload_fluid(c, nf, px, py, vel, vel + ntz, drho_dt, mass, nullptr, true);
+    std::vector<int> wid((size_t)std::max(nw, 1));
+    for (int k = 0; k < nw; ++k) wid[k] = nf + k;
+    upload_walls(c, nw, px + nf, py + nf, mass + nf, wall_vel + nf, wall_vel + ntz + nf, wid.data(), true);
+    init_clock(c, nf, t0, step0);
     read_clock(c);
 }
 
 // emit the MEX-convention pair list of the current ordering into the ctx-held buffers
-void emit_pairs(sphx_ctx *c)
+void emit_pairs(sphx_ctx *c, bool fill)
 {
     const int nf = c->nf;
     hipStream_t s = c->stream;
     DevBuf<int> cnt(nf), off((size_t)nf + 1);
     const FluidSet &fs = c->set[c->cur];
+    const Clock *clk = c->clock.get();
     const dim3 g1(div_up(nf, kBlock)), b1(kBlock);
-    hipLaunchKernelGGL(k_pairs<0>, g1, b1, 0, s, c->grid, c->phys, nf, fs, c->walls, cnt.get(), (const int *)nullptr,
+    hipLaunchKernelGGL(k_pairs<0>, g1, b1, 0, s, clk, c->grid, c->phys, fs, c->walls, cnt.get(), (const int *)nullptr,
                        (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr);
-    hipLaunchKernelGGL(k_scan_only, dim3(1), dim3(kScanBlock), 0, s, (const int *)cnt.get(), off.get(), nf);
+    hipLaunchKernelGGL(k_scan_only, dim3(1), dim3(kScanBlock), 0, s, (const Clock *)nullptr, 0, (const int *)cnt.get(), off.get(), nf);
     int total = 0;
     SPHX_HIP(hipMemcpyAsync(&total, off.get() + nf, sizeof(int), hipMemcpyDeviceToHost, s));
     SPHX_HIP(hipStreamSynchronize(s));
-    const size_t n = (size_t)total, m = n ? n : 1;
+    c->pl_n = (size_t)total;
+    if (!fill) return;
+    const size_t m = c->pl_n ? c->pl_n : 1;
     c->pl_i.alloc(m); c->pl_j.alloc(m); c->pl_dx.alloc(m); c->pl_dy.alloc(m); c->pl_r.alloc(m); c->pl_W.alloc(m); c->pl_dW.alloc(m);
-    hipLaunchKernelGGL(k_pairs<1>, g1, b1, 0, s, c->grid, c->phys, nf, fs, c->walls, (int *)nullptr, (const int *)off.get(),
+    hipLaunchKernelGGL(k_pairs<1>, g1, b1, 0, s, clk, c->grid, c->phys, fs, c->walls, (int *)nullptr, (const int *)off.get(),
                        c->pl_i.get(), c->pl_j.get(), c->pl_dx.get(), c->pl_dy.get(), c->pl_r.get(), c->pl_W.get(), c->pl_dW.get());
     SPHX_HIP(hipGetLastError());
     SPHX_HIP(hipStreamSynchronize(s));
-    c->pl_n = n;
     c->pl_valid = true;
 }
 
-thread_local sphx_ctx *g_search_ctx = nullptr;  // owns the temporary context of sphx_neighbor_search until fetch
-thread_local sphx_ctx *g_fetch_src = nullptr;   // context whose pair list the next sphx_neighbor_fetch copies out
+double host_dt_unclipped(const sphx_ctx *c, double vmax)
+{
+    const double hh = c->phys.kc.h;
+    return std::min(std::min(0.25 * hh / std::max(c->phys.c_f + vmax, 1e-12), 0.125 * hh * hh / std::max(c->phys.nu, 1e-12)),
+                    0.25 * std::sqrt(hh / std::max(std::fabs(c->phys.g), 1e-12)));
+}
+
+void throw_on_status(const sphx_ctx *c)
+{
+    if (c->h_clock->status == SPHX_ERR_GRID)
+        throw Error(SPHX_ERR_GRID, "SPHX:Ctx:grid", "neighbour list / slab buffer capacity exceeded on device");
+    if (c->h_clock->status != 0)
+        throw Error(c->h_clock->status, "SPHX:Ctx:diverged", "device step loop raised a status (non-finite velocity)");
+}
 
 }  // namespace
 
@@ -1177,20 +612,18 @@ SPHX_EXPORT int sphx_ctx_advance(sphx_ctx *c, double t_target, int64_t max_steps
 {
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    require(!c->is_slab, "SPHX:Ctx:slab", "slab contexts are advanced with sphx_slab_compute/finish");
     for (int guard = 0; guard < 1000000; ++guard) {
         hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target,
-                           (long long)max_steps, c->cur);
-        // estimate how many slots this call needs from the current dt, then over-provision one graph
+                           (long long)max_steps, c->cur, (const double *)nullptr);
+        // how many slots this call needs, from the unclipped dt; over-provision to whole graphs when unlimited
         const Clock &k = *c->h_clock;
-        const double hh = c->phys.kc.h;
-        const double dt_est = std::min(std::min(0.25 * hh / std::max(c->phys.c_f + k.vmax, 1e-12),
-                                                0.125 * hh * hh / std::max(c->phys.nu, 1e-12)),
-                                       0.25 * std::sqrt(hh / std::max(std::fabs(c->phys.g), 1e-12)));
+        const double dt_est = host_dt_unclipped(c, k.vmax);
         double want = std::ceil(std::max(0.0, std::min(t_target, k.t_end) - k.t) / std::max(dt_est, 1e-12)) + 1.0;
-        if (max_steps > 0) want = std::min(want, (double)max_steps);
         want = std::min(want, 4096.0);
         int64_t slots = (int64_t)want;
-        if (slots > c->spg) slots = ((slots + c->spg - 1) / c->spg) * c->spg;
+        if (max_steps > 0 && slots >= max_steps) slots = max_steps;  // exact: no no-op slots
+        else if (!c->profiling && slots > c->spg) slots = ((slots + c->spg - 1) / c->spg) * c->spg;
         if (slots < 1) slots = 1;
         const int64_t step_before = c->h_clock->step;
         enqueue_slots(c, slots);
@@ -1202,11 +635,10 @@ SPHX_EXPORT int sphx_ctx_advance(sphx_ctx *c, double t_target, int64_t max_steps
         }
         if (c->h_clock->status != 0) break;
         if (!(c->h_clock->t < t_target - 1e-12)) break;
-        if (!(c->h_clock->t < c->h_clock->t_end - 1e-12) && executed == 0) break;
+        if (!(c->h_clock->t < c->h_clock->t_end - 1e-12)) break;
     }
     fill_status(c, status);
-    if (c->h_clock->status != 0)
-        throw Error(c->h_clock->status, "SPHX:Ctx:diverged", "device step loop raised a status (non-finite velocity)");
+    throw_on_status(c);
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -1215,11 +647,10 @@ SPHX_EXPORT int sphx_ctx_enqueue_steps(sphx_ctx *c, int64_t n_steps)
 {
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    require(!c->is_slab, "SPHX:Ctx:slab", "slab contexts are advanced with sphx_slab_compute/finish");
     require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
-    // parity of the first slot = parity of the state after everything already enqueued; callers of this
-    // entry point run fixed step counts, so cur advances deterministically
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end,
-                       (long long)n_steps, c->cur);
+                       (long long)n_steps, c->cur, (const double *)nullptr);
     enqueue_slots(c, n_steps);
     c->cur = (int)((c->cur + n_steps) & 1);  // provisional; read_clock() recomputes from the device step count
     return SPHX_OK;
@@ -1230,8 +661,10 @@ SPHX_EXPORT int sphx_ctx_sync(sphx_ctx *c, sphx_status *status)
 {
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    require(!c->is_slab, "SPHX:Ctx:slab", "use sphx_slab_sync on a slab context");
     read_clock(c);
     fill_status(c, status);
+    throw_on_status(c);
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -1241,6 +674,7 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
 {
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    require(!c->is_slab, "SPHX:Ctx:slab", "use sphx_slab_snapshot on a slab context");
     read_clock(c);
     const bool need_outputs = rho || p || force || force_prior || Vol || B;
     if (need_outputs && !c->have_step_outputs)
@@ -1250,7 +684,7 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
     const FluidSet &fs = c->set[c->cur];
     const int *id_old = c->set[1 - c->cur].id;  // ordering the step outputs are stored in
     DevBuf<double> stage((size_t)4 * nt);
-    const dim3 gf(div_up(nf, kBlock)), gw(div_up(std::max(nw, 1), kBlock)), gt(div_up(nt, kBlock)), b(kBlock);
+    const dim3 gf(div_up(nf, kBlock)), gw(div_up(std::max(nw, 1), kBlock)), b(kBlock);
     auto col = [&](int cidx) { return stage.get() + (size_t)cidx * nt; };
     auto unsort_f = [&](const int *id, const double *src, int cidx) {
         hipLaunchKernelGGL(k_unsort, gf, b, 0, s, nf, id, src, col(cidx));
@@ -1265,7 +699,6 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
         SPHX_HIP(hipMemcpyAsync(host, stage.get(), (size_t)ncol * nt * sizeof(double), hipMemcpyDeviceToHost, s));
         SPHX_HIP(hipStreamSynchronize(s));
     };
-    (void)gt;
     if (pos) { unsort_f(fs.id, fs.x, 0); unsort_f(fs.id, fs.y, 1); unsort_w(c->wx.get(), 0); unsort_w(c->wy.get(), 1); out(pos, 2); }
     if (vel) { unsort_f(fs.id, fs.vx, 0); unsort_f(fs.id, fs.vy, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(vel, 2); }
     if (drho_dt) { unsort_f(fs.id, fs.drho, 0); fill_w(0, 0.0); out(drho_dt, 1); }
@@ -1288,16 +721,16 @@ SPHX_EXPORT int sphx_ctx_monitor(sphx_ctx *c, double *tau_bottom, double *tau_to
 {
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    require(!c->is_slab, "SPHX:Ctx:slab", "monitors are not available on a slab context");
     read_clock(c);
     hipStream_t s = c->stream;
-    const int nf = c->nf;
     const FluidSet &fs = c->set[c->cur];
     if (tau_bottom || tau_top) {
         if (!c->have_step_outputs)
             throw Error(SPHX_ERR_STATE, "SPHX:Ctx:monitor", "wall shear needs Vol/B of a completed step");
-        const int nblk = (int)div_up(nf, kBlock);
-        hipLaunchKernelGGL(k_wall_shear, dim3(nblk), dim3(kBlock), 0, s, c->grid, c->phys, nf, fs, c->tmp, c->walls, 1,
-                           c->tau_part.get());
+        const int nblk = c->n_blocks_flat;
+        hipLaunchKernelGGL(k_wall_shear, dim3(nblk), dim3(kBlock), 0, s, (const Clock *)c->clock.get(), c->grid, c->phys, fs,
+                           c->tmp, c->walls, c->tau_part.get());
         hipLaunchKernelGGL(k_tau_final, dim3(1), dim3(kScanBlock), 0, s, nblk, (const double *)c->tau_part.get(),
                            c->phys.DL, c->tau_out.get());
         double h[2];
@@ -1307,15 +740,8 @@ SPHX_EXPORT int sphx_ctx_monitor(sphx_ctx *c, double *tau_bottom, double *tau_to
         if (tau_top) *tau_top = h[1];
     }
     if (n_pairs) {
-        DevBuf<int> cnt(nf), off((size_t)nf + 1);
-        hipLaunchKernelGGL(k_pairs<0>, dim3(div_up(nf, kBlock)), dim3(kBlock), 0, s, c->grid, c->phys, nf, fs, c->walls,
-                           cnt.get(), (const int *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr,
-                           (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
-        hipLaunchKernelGGL(k_scan_only, dim3(1), dim3(kScanBlock), 0, s, (const int *)cnt.get(), off.get(), nf);
-        int total = 0;
-        SPHX_HIP(hipMemcpyAsync(&total, off.get() + nf, sizeof(int), hipMemcpyDeviceToHost, s));
-        SPHX_HIP(hipStreamSynchronize(s));
-        *n_pairs = (double)total;
+        emit_pairs(c, false);
+        *n_pairs = (double)c->pl_n;
     }
     SPHX_HIP(hipGetLastError());
     return SPHX_OK;
@@ -1326,8 +752,9 @@ SPHX_EXPORT int sphx_ctx_neighbor_list(sphx_ctx *c, size_t *n_pairs)
 {
     SPHX_TRY
     require(c != nullptr && n_pairs != nullptr, "SPHX:Ctx:null", "ctx / n_pairs must not be NULL");
+    require(!c->is_slab, "SPHX:Ctx:slab", "pair lists are not available on a slab context");
     read_clock(c);
-    emit_pairs(c);
+    emit_pairs(c, true);
     *n_pairs = c->pl_n;
     g_fetch_src = c;
     return SPHX_OK;
@@ -1349,7 +776,7 @@ SPHX_EXPORT int sphx_neighbor_search(const double *pos, int n_fluid, int n_total
         std::vector<double> zeros2(2 * nt, 0.0), ones(nt, 1.0);
         c = new sphx_ctx();
         ctx_setup(c, &prm, n_fluid, n_total, pos, zeros2.data(), zeros2.data(), ones.data(), zeros2.data(), 0.0, 0);
-        emit_pairs(c);
+        emit_pairs(c, true);
         *n_pairs = c->pl_n;
         if (g_search_ctx) delete g_search_ctx;
         g_search_ctx = c;
@@ -1440,6 +867,272 @@ SPHX_EXPORT int sphx_ctx_tuning(sphx_ctx *c, int *lanes_per_particle, int *steps
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     if (lanes_per_particle) *lanes_per_particle = c->lpp;
     if (steps_per_graph) *steps_per_graph = c->spg;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+// =================================================================================================
+// x-slab contexts (multi-GPU): one context per rank holds the particles of its column range plus
+// `halo_cols` columns of copies on either side, in an OPEN grid window.  Per step:
+//   sphx_slab_compute : k_density..k_continuity on everything held, local max|v| of owned particles,
+//                       pack keep / send-left / send-right
+//   (caller: exchange the two messages with the ring neighbours, all-reduce max|v|)
+//   sphx_slab_finish  : unpack, clock update with the global max|v|, cell rebuild.
+// Validity: with halo H columns (each >= 2h wide) pass A is exact on columns >= own-(H-1), pass B on
+// >= own-(H-2), the force pass on >= own-(H-3) and the continuity pass on the owned columns for H = 4;
+// whatever is computed on halo copies is discarded (their owner sends fresh state).
+// =================================================================================================
+namespace {
+
+struct HostParticles {
+    std::vector<double> x, y, vx, vy, drho, mass;
+    std::vector<int> id;
+    void push(double X, double Y, double VX, double VY, double D, double M, int I)
+    {
+        x.push_back(X); y.push_back(Y); vx.push_back(VX); vy.push_back(VY); drho.push_back(D); mass.push_back(M); id.push_back(I);
+    }
+};
+
+void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, const double *pos, const double *vel,
+                const double *drho_dt, const double *mass, const double *wall_vel, double t0, int64_t step0, int rank,
+                int n_ranks, int halo_cols, void *stream)
+{
+    common_checks(prm, n_fluid, n_total);
+    require(n_ranks >= 2 && rank >= 0 && rank < n_ranks, "SPHX:Slab:rank", "slab contexts need n_ranks >= 2 and 0 <= rank < n_ranks");
+    require(halo_cols >= 4, "SPHX:Slab:halo", "halo_cols must be >= 4 (four dependent neighbour passes per step)");
+    ensure_device();
+    c->prm = *prm;
+    c->is_slab = true;
+    c->rank = rank; c->n_ranks = n_ranks; c->halo_cols = halo_cols;
+    c->nf = n_fluid; c->nt = n_total; c->nw = n_total - n_fluid;
+    const size_t ntz = (size_t)n_total;
+    const double *px = pos, *py = pos + ntz;
+    double y_min, y_max;
+    y_extent(py, n_total, y_min, y_max);
+    const double cs = 2.0 * prm->h, DL = prm->DL;
+    const int ncx_g = (int)std::floor(DL / cs);
+    const double csx = DL / ncx_g;
+    const int H = halo_cols;
+    auto col_lo = [&](int r) { return (int)(((long long)r * ncx_g) / n_ranks); };
+    c->col0 = col_lo(rank);
+    c->col1 = col_lo(rank + 1);
+    for (int r = 0; r < n_ranks; ++r)
+        require(col_lo(r + 1) - col_lo(r) >= H + 1, "SPHX:Slab:width",
+                "every slab must own at least halo_cols+1 cell columns (use fewer ranks or a longer channel)");
+    require((c->col1 - c->col0) + 2 * H < ncx_g, "SPHX:Slab:width", "slab window would cover the whole period");
+
+    Grid g{};
+    g.ncx = (c->col1 - c->col0) + 2 * H;
+    g.ncy = (int)std::ceil((y_max - y_min + 1e-12) / cs) + 1;
+    g.ncells = g.ncx * g.ncy;
+    g.periodic = 0;
+    g.DL = DL;
+    g.half_DL = std::numeric_limits<double>::infinity();
+    g.x0 = (double)(c->col0 - H) * csx;
+    g.y0 = y_min;
+    g.inv_csx = (double)ncx_g / DL;
+    g.inv_csy = 1.0 / cs;
+    g.own_lo = (double)c->col0 * csx;
+    g.own_hi = (rank == n_ranks - 1) ? DL : (double)c->col1 * csx;
+    c->grid = g;
+    c->phys = make_phys(prm);
+    const double win_lo = g.x0, win_hi = g.x0 + (double)g.ncx * csx;
+
+    // select the particles (and periodic images) inside this rank's window
+    HostParticles hf, hw;
+    std::vector<double> wvx, wvy;
+    for (int i = 0; i < n_total; ++i) {
+        const double xw = px[i] - std::floor(px[i] / DL) * DL;
+        for (int im = -1; im <= 1; ++im) {
+            const double xs = xw + im * DL;
+            if (!(xs >= win_lo && xs < win_hi)) continue;
+            if (i < n_fluid) hf.push(xs, py[i], vel[i], vel[ntz + i], drho_dt[i], mass[i], i);
+            else { hw.push(xs, py[i], 0, 0, 0, mass[i], i); wvx.push_back(wall_vel[i]); wvy.push_back(wall_vel[ntz + i]); }
+        }
+    }
+    const int n_local = (int)hf.x.size(), nw_local = (int)hw.x.size();
+    // capacities: message = (H+2) columns at twice the mean column load; arrays = window at 1.5x + messages
+    const double per_col = (double)n_fluid / ncx_g;
+    c->msg_cap = (int)(2.0 * (H + 2) * per_col) + 1024;
+    const int cap = (int)(1.5 * per_col * g.ncx) + 2 * c->msg_cap + 1024;
+    require(n_local <= cap, "SPHX:Slab:capacity", "initial slab population exceeds capacity");
+
+    c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(n_local);
+    check_lpp(c->lpp);
+    c->spg = 2;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else SPHX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    SPHX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_clock), sizeof(Clock), hipHostMallocDefault));
+    ctx_alloc(c, cap);
+    upload_fluid(c, n_local, hf.x.data(), hf.y.data(), hf.vx.data(), hf.vy.data(), hf.drho.data(), hf.mass.data(),
+                 hf.id.data(), false);
+    upload_walls(c, nw_local, hw.x.data(), hw.y.data(), hw.mass.data(), wvx.data(), wvy.data(), hw.id.data(), false);
+
+    c->kx.alloc(cap); c->ky.alloc(cap); c->kvx.alloc(cap); c->kvy.alloc(cap); c->kdrho.alloc(cap); c->kmass.alloc(cap);
+    c->kid.alloc(cap); c->counters.alloc(3); c->n_new.alloc(1);
+    c->counters.zero(c->stream);
+    SlabPack p{};
+    p.counters = c->counters.get();
+    p.kx = c->kx.get(); p.ky = c->ky.get(); p.kvx = c->kvx.get(); p.kvy = c->kvy.get(); p.kdrho = c->kdrho.get();
+    p.kmass = c->kmass.get(); p.kid = c->kid.get();
+    p.halo_w = (double)H * csx;
+    p.shift_l = (rank == 0) ? DL : 0.0;             // my left neighbour is the last slab: it sees me at x + DL
+    p.shift_r = (rank == n_ranks - 1) ? -DL : 0.0;  // my right neighbour is the first slab
+    p.msg_cap = c->msg_cap;
+    p.keep_cap = cap;
+    c->pack = p;
+    init_clock(c, n_local, t0, step0);
+    read_clock(c);
+}
+
+}  // namespace
+
+SPHX_EXPORT int sphx_slab_create(sphx_ctx **out, const sphx_params *prm, int n_fluid, int n_total, const double *pos,
+                                 const double *vel, const double *drho_dt, const double *mass, const double *wall_vel,
+                                 double t0, int64_t step0, int rank, int n_ranks, int halo_cols, void *hip_stream)
+{
+    sphx_ctx *c = nullptr;
+    try {
+        require(out != nullptr, "SPHX:Ctx:out", "ctx output pointer must not be NULL");
+        c = new sphx_ctx();
+        slab_setup(c, prm, n_fluid, n_total, pos, vel, drho_dt, mass, wall_vel, t0, step0, rank, n_ranks, halo_cols, hip_stream);
+        *out = c;
+        return SPHX_OK;
+    } catch (const Error &e) {
+        delete c;
+        return report(e);
+    } catch (const std::exception &e) {
+        delete c;
+        return report_unknown(e);
+    }
+}
+
+SPHX_EXPORT int sphx_slab_layout(sphx_ctx *c, int64_t *msg_doubles, int *col0, int *col1, int *n_local, int *capacity)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    if (msg_doubles) *msg_doubles = 1 + 7 * (int64_t)c->msg_cap;
+    if (col0) *col0 = c->col0;
+    if (col1) *col1 = c->col1;
+    if (n_local) *n_local = c->h_clock->n;
+    if (capacity) *capacity = c->cap;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+// local max |v| of owned particles at the current state -> vmax_dev[0] (device pointer); async.
+SPHX_EXPORT int sphx_slab_local_vmax(sphx_ctx *c, double *vmax_dev)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab && vmax_dev != nullptr, "SPHX:Slab:ctx", "not a slab context");
+    const FluidSet &fs = c->set[c->cur];
+    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, c->stream, c->clock.get(), c->grid, (const double *)fs.x,
+                       (const double *)fs.vx, (const double *)fs.vy, vmax_dev);
+    SPHX_HIP(hipGetLastError());
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+// arm the clock with the all-reduced max |v| (device pointer); async.
+SPHX_EXPORT int sphx_slab_prepare(sphx_ctx *c, double t_target, int64_t max_steps, const double *vmax_global_dev)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target, (long long)max_steps,
+                       c->cur, vmax_global_dev);
+    SPHX_HIP(hipGetLastError());
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *send_right_dev, double *vmax_local_dev)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    require(send_left_dev && send_right_dev && vmax_local_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
+    const int q = c->cur;
+    const Clock *clk = c->clock.get();
+    launch_physics_any(c, q, 0);
+    launch(c, "k_vmax_reduce", k_vmax_reduce, dim3(1), dim3(kScanBlock), clk, q, c->n_blocks_particles,
+           (const double *)c->vpart.get(), vmax_local_dev);
+    SlabPack p = c->pack;
+    p.send_l = send_left_dev;
+    p.send_r = send_right_dev;
+    launch(c, "k_slab_pack", k_slab_pack, dim3(c->n_blocks_flat), dim3(kBlock), clk, q, c->grid, c->set[q], c->tmp, p);
+    launch(c, "k_slab_seal", k_slab_seal, dim3(1), dim3(1), clk, q, p);
+    SPHX_HIP(hipGetLastError());
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const double *recv_right_dev,
+                                 const double *vmax_global_dev)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    require(recv_left_dev && recv_right_dev && vmax_global_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
+    const int q = c->cur;
+    Clock *clk = c->clock.get();
+    const dim3 g1(c->n_blocks_flat), bp(kBlock);
+    launch(c, "k_slab_unpack", k_slab_unpack, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), bp, (const Clock *)clk, q, c->pack,
+           recv_left_dev, recv_right_dev, c->n_new.get(), c->flags.get());
+    // clock: t += dt, new particle count, next dt from the global max |v|.  It arms run[1-q]; the remaining
+    // kernels of this slot still test run[q], and from here on clk->n is the new particle count.
+    launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
+           vmax_global_dev, (const int *)c->flags.get(), (const int *)nullptr, (int *)nullptr, 0, (const int *)c->n_new.get());
+    launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, q, c->grid, 0, (const double *)c->kx.get(), (const double *)c->ky.get(),
+           c->cellid.get(), c->count.get());
+    launch_cell_scan(c, q, c->set[1 - q].start);
+    const double *src[6] = {c->kx.get(), c->ky.get(), c->kvx.get(), c->kvy.get(), c->kdrho.get(), c->kmass.get()};
+    launch_scatter_reorder(c, q, src, c->kid.get(), nullptr);
+    launch(c, "k_slab_reset", k_slab_reset, dim3(1), dim3(1), (const Clock *)clk, q, c->counters.get());
+    SPHX_HIP(hipGetLastError());
+    c->cur ^= 1;
+    c->slab_steps_enqueued += 1;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+// wait for the stream, verify that every enqueued slab step really executed, report the clock
+SPHX_EXPORT int sphx_slab_sync(sphx_ctx *c, sphx_status *status)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    SPHX_HIP(hipMemcpyAsync(c->h_clock, c->clock.get(), sizeof(Clock), hipMemcpyDeviceToHost, c->stream));
+    SPHX_HIP(hipStreamSynchronize(c->stream));
+    c->timer.collect();
+    fill_status(c, status);
+    const int64_t executed = (int64_t)c->h_clock->step - c->step_at_cur0;
+    throw_on_status(c);
+    if (executed != c->slab_steps_enqueued)
+        throw Error(SPHX_ERR_STATE, "SPHX:Slab:overrun", "a slab step was enqueued after the loop had stopped");
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+// copy the current particles of the slab to host arrays of `capacity` entries; *n = count.  owned[i]
+// tells whether particle i belongs to this rank (the rest are halo copies).
+SPHX_EXPORT int sphx_slab_snapshot(sphx_ctx *c, int capacity, int *n, double *x, double *y, double *vx, double *vy,
+                                   double *drho, int *id, int *owned)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab && n != nullptr, "SPHX:Slab:ctx", "not a slab context");
+    SPHX_HIP(hipMemcpyAsync(c->h_clock, c->clock.get(), sizeof(Clock), hipMemcpyDeviceToHost, c->stream));
+    SPHX_HIP(hipStreamSynchronize(c->stream));
+    const int m = c->h_clock->n;
+    *n = m;
+    require(capacity >= m, "SPHX:Slab:capacity", "snapshot arrays are too short");
+    const FluidSet &fs = c->set[c->cur];
+    hipStream_t s = c->stream;
+    auto dl = [&](const void *src, void *dst, size_t bytes) {
+        if (dst && m) SPHX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    };
+    std::vector<double> hx((size_t)std::max(m, 1));
+    dl(fs.x, hx.data(), (size_t)m * 8); dl(fs.x, x, (size_t)m * 8); dl(fs.y, y, (size_t)m * 8); dl(fs.vx, vx, (size_t)m * 8);
+    dl(fs.vy, vy, (size_t)m * 8); dl(fs.drho, drho, (size_t)m * 8); dl(fs.id, id, (size_t)m * 4);
+    SPHX_HIP(hipStreamSynchronize(s));
+    if (owned)
+        for (int i = 0; i < m; ++i) owned[i] = (hx[i] >= c->grid.own_lo && hx[i] < c->grid.own_hi) ? 1 : 0;
     return SPHX_OK;
     SPHX_CATCH
 }
