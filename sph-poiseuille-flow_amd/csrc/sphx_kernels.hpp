@@ -860,7 +860,9 @@ __global__ __launch_bounds__(kBlock) void k_fill(int n, double *dst, double v)
 
 // ---------------------------------------------------------------------------------------------
 // x-slab halo exchange (multi-GPU): pack the end-of-step state of OWNED particles into
-//   keep  : still inside [own_lo, own_hi)            -> compacted in place for the next step
+//   keep  : still inside this rank's window [win_lo, win_hi) -> compacted for the next step (a particle
+//           that crossed into a neighbour's columns stays here as a halo copy: its new owner did not
+//           own it during this step and therefore does not send it back yet)
 //   sendL : x_new < own_lo + halo_w  (shifted by shift_l: +DL on the first slab)
 //   sendR : x_new >= own_hi - halo_w (shifted by shift_r: -DL on the last slab)
 // A message is double[1 + 7*cap]: count, then x,y,vx,vy,drho,mass,id blocks of `cap`.
@@ -871,7 +873,7 @@ struct SlabPack {
     int *counters;             // [3]: keep, left, right (zeroed by k_slab_unpack of the previous step)
     double *kx, *ky, *kvx, *kvy, *kdrho, *kmass;  // keep arrays (compacted)
     int *kid;
-    double halo_w, shift_l, shift_r;
+    double halo_w, shift_l, shift_r, win_lo, win_hi;
     int msg_cap, keep_cap;
 };
 
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(const Clock *clk, int q, G
     if (!(x_ref >= g.own_lo && x_ref < g.own_hi)) return;  // halo copy
     const double xn = t.xn[i], yn = t.yn[i], vxn = t.vxn[i], vyn = t.vyn[i], dr = t.drhon[i], m = s.mass[i];
     const int id = s.id[i];
-    if (xn >= g.own_lo && xn < g.own_hi) {
+    if (xn >= p.win_lo && xn < p.win_hi) {
         const int k = atomicAdd(&p.counters[0], 1);
         if (k < p.keep_cap) {
             p.kx[k] = xn; p.ky[k] = yn; p.kvx[k] = vxn; p.kvy[k] = vyn; p.kdrho[k] = dr; p.kmass[k] = m; p.kid[k] = id;

@@ -978,6 +978,8 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     p.halo_w = (double)H * csx;
     p.shift_l = (rank == 0) ? DL : 0.0;             // my left neighbour is the last slab: it sees me at x + DL
     p.shift_r = (rank == n_ranks - 1) ? -DL : 0.0;  // my right neighbour is the first slab
+    p.win_lo = win_lo;
+    p.win_hi = win_hi;
     p.msg_cap = c->msg_cap;
     p.keep_cap = cap;
     c->pack = p;
