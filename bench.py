@@ -102,6 +102,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libsphx has no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     pkg = importlib.import_module(PKG)

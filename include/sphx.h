@@ -198,6 +198,9 @@ int sphx_ctx_profile_read(sphx_ctx *ctx, int capacity, const char **names, doubl
 /* The launch shape the context chose (lanes cooperating per particle, steps per hipGraph replay). */
 int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph);
 
+/* Global particle counts and the cell grid the context built. */
+int sphx_ctx_info(sphx_ctx *ctx, int *n_fluid, int *n_wall, int *n_cell_x, int *n_cell_y);
+
 /* ------------------------------------------------------------------------------------------------
  * 3. x-slab contexts (multi-GPU).  The channel is cut into n_ranks slabs of whole cell columns; each
  *    rank (one process per GPU) holds its columns plus halo_cols columns of copies on either side.

@@ -256,7 +256,12 @@ def bench_main(args, rank, world, local_rank):
     import torch.distributed as dist
     pkg = importlib.import_module(__package__)
     cfg, geo = pkg.config, pkg.geometry
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    backend = os.environ.get("SPHX_DIST_BACKEND", "nccl")  # "gloo": rehearsal with ranks sharing one GPU
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
     name = args.workload or "C2"
     workloads = {"C1": dict(dp=0.04, DL=3.0), "C2": dict(dp=0.025, DL=3.0), "C3": dict(dp=0.01, DL=6.0),
                  "C4": dict(dp=0.005, DL=12.0), "C5": dict(dp=0.002, DL=24.0)}
@@ -280,7 +285,8 @@ def bench_main(args, rank, world, local_rank):
     st = drv.run_steps(args.steps)
     torch.cuda.synchronize()
     dist.barrier()
-    seconds = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=eng.device)
+    seconds = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                           device=eng.device if backend == "nccl" else "cpu")
     dist.all_reduce(seconds, op=dist.ReduceOp.MAX)
     seconds = float(seconds.item())
     nt = parts["n_total"]
