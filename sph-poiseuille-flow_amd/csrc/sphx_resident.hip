@@ -209,6 +209,13 @@ void launch_step(sphx_ctx *c, int q)
     Clock *clk = c->clock.get();
     const FluidSet &s = c->set[q];
     const FluidSet &d = c->set[1 - q];
+    const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
+    if (!c->big_scan && c->cap <= kSmallRebuildN) {  // whole rebuild by one workgroup
+        launch(c, "k_rebuild_small", k_rebuild_small, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_blocks_particles,
+               (const double *)c->vpart.get(), (const int *)c->flags.get(), c->count.get(), d.start, c->grid.ncells,
+               (const int *)c->cellid.get(), c->perm.get(), reorder_args(src, s.id, d, c->tmp.src_of));
+        return;
+    }
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_blocks_particles,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(),
@@ -223,7 +230,6 @@ void launch_step(sphx_ctx *c, int q)
         launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                (const int *)tile_off, c->grid.ncells, c->n_tiles);
     }
-    const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
     launch_scatter_reorder(c, q, src, s.id, c->tmp.src_of);
 }
 
