@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_FLUID = {"k_density": 40, "k_kgc": 56, "k_forces": 112 + 192, "k_continuity": 104,
                    "k_clock_scan": 0, "k_scatter": 8, "k_reorder": 16}
 BYTES_PER_WALL = {"k_density": 24, "k_kgc": 24, "k_forces": 48, "k_continuity": 24}
+for _k in ("k_density", "k_kgc", "k_forces", "k_continuity"):  # LDS-tiled variants: same algorithmic bytes
+    BYTES_PER_FLUID[_k + "_t"] = BYTES_PER_FLUID[_k]
+    BYTES_PER_WALL[_k + "_t"] = BYTES_PER_WALL[_k]
 STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
 
 
@@ -86,6 +89,7 @@ def main():
     ap.add_argument("--workload", default=None, help="C1..C5 or 'dp=0.01,DL=6' (default: C2 at 1 GPU)")
     ap.add_argument("--lpp", type=int, default=0, help="lanes per particle (0 = auto)")
     ap.add_argument("--spg", type=int, default=0, help="steps per hipGraph replay (0 = auto)")
+    ap.add_argument("--tile", type=int, default=0, help="cells per LDS tile (0 = auto, -1 = list-walking kernels only)")
     ap.add_argument("--profile-steps", type=int, default=200, help="eager steps timed per kernel with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -124,7 +128,7 @@ def main():
         start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
 
     ctx = capi.Context(prm, nf, nt, pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9,
-                       lanes_per_particle=args.lpp, steps_per_graph=args.spg)
+                       lanes_per_particle=args.lpp, steps_per_graph=args.spg, tile_cells=args.tile)
     info = ctx.info()
     tuning = ctx.tuning()
     # warm-up (untimed): includes graph capture/instantiation

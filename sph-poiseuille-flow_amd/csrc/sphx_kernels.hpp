@@ -188,10 +188,6 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     const bool active = i < n;
     double s_in = 0.0, s_ct = 0.0;
     int cnt = 0;
-    // the accepted neighbours are first collected in LDS (one column per thread) and written out row by
-    // row afterwards, so the global stores are full 256-byte rows instead of 64 scattered words
-    constexpr int kCap = (64 / LPP) > 16 ? (64 / LPP) : 16;
-    __shared__ int s_list[kCap * kBlock];
     if (active) {
         const double xi = s.x[i], yi = s.y[i];
         int cx, cy;
@@ -201,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
             const double r2 = dx * dx + dy * dy;
             if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                 s_in += spline_W(ph.kc, sqrt(r2));
-                if (cnt < kCap) s_list[cnt * kBlock + threadIdx.x] = k;
+                if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = k;
                 ++cnt;
             }
         });
@@ -212,12 +208,9 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, sqrt(r2)) * w.Vol[k];
             });
         }
-        if (cnt > kCap) { atomicOr(t.flags, 1); cnt = kCap; }
+        if (cnt > t.nl_cap) { atomicOr(t.flags, 1); cnt = t.nl_cap; }
     }
-    if (tid < t.nl_stride) {
-        t.nl_cnt[tid] = cnt;
-        for (int m = 0; m < cnt; ++m) t.nl_idx[(size_t)m * t.nl_stride + tid] = s_list[m * kBlock + threadIdx.x];
-    }
+    if (tid < t.nl_stride) t.nl_cnt[tid] = cnt;
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {

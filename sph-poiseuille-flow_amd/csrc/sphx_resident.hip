@@ -8,6 +8,7 @@
 
 #include "sphx_common.hpp"
 #include "sphx_kernels.hpp"
+#include "sphx_kernels_tiled.hpp"
 
 namespace sphx {
 
@@ -58,6 +59,11 @@ struct sphx_ctx {
     int64_t step_at_cur0 = 0;
     bool have_step_outputs = false;
     bool big_scan = false;
+    bool tiled = false;          // LDS-tiled neighbour passes (large particle counts)
+    TileCfg tcfg{};
+    int n_vpart = 0;             // entries of vpart the clock kernel reduces
+    DevBuf<unsigned short> nl16;
+    bool fused_rebuild = false;  // measured slower than three launches at 5 k particles (48 us vs 21 us)
     int n_tiles = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -137,6 +143,23 @@ void launch(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, Args
     }
 }
 
+template <typename K, typename... Args>
+void launch_s(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, size_t shmem, Args... args)
+{
+    if (c->profiling || c->capturing_profile) {
+        KernelTimer::Pending p;
+        p.idx = c->timer.index_of(name);
+        SPHX_HIP(hipEventCreate(&p.a));
+        SPHX_HIP(hipEventCreate(&p.b));
+        SPHX_HIP(hipEventRecord(p.a, c->stream));
+        hipLaunchKernelGGL(kernel, grid, block, shmem, c->stream, args...);
+        SPHX_HIP(hipEventRecord(p.b, c->stream));
+        (c->capturing_profile ? c->timer.graph_evs : c->timer.pending).push_back(p);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shmem, c->stream, args...);
+    }
+}
+
 ReorderArgs reorder_args(const double *const src[6], const int *id_src, const FluidSet &d, int *src_of)
 {
     ReorderArgs ra{};
@@ -155,6 +178,21 @@ void launch_physics(sphx_ctx *c, int q, int do_hist)
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
     const FluidSet &s = c->set[q];
+    if (c->tiled) {
+        const TileCfg tc = c->tcfg;
+        const dim3 gt(c->grid.ncx * tc.nseg);
+        const size_t H = (size_t)tc.hcap * sizeof(double);
+        unsigned short *nl = c->nl16.get();
+        launch_s(c, "k_density_t", k_density_t<LPP>, gt, bp, 2 * H + 3 * (size_t)(tc.ct + 4) * sizeof(int), clk, q, c->grid,
+                 c->phys, s, c->tmp, c->walls, tc, nl);
+        launch_s(c, "k_kgc_t", k_kgc_t<LPP>, gt, bp, 3 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls, tc,
+                 (const unsigned short *)nl);
+        launch_s(c, "k_forces_t", k_forces_t<LPP>, gt, bp, 11 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls, tc,
+                 (const unsigned short *)nl);
+        launch_s(c, "k_continuity_t", k_continuity_t<LPP>, gt, bp, 5 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls,
+                 do_hist, tc, (const unsigned short *)nl);
+        return;
+    }
     launch(c, "k_density", k_density<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
     launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
     launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
@@ -210,21 +248,21 @@ void launch_step(sphx_ctx *c, int q)
     const FluidSet &s = c->set[q];
     const FluidSet &d = c->set[1 - q];
     const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
-    if (!c->big_scan && c->cap <= kSmallRebuildN) {  // whole rebuild by one workgroup
-        launch(c, "k_rebuild_small", k_rebuild_small, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_blocks_particles,
+    if (c->fused_rebuild && !c->big_scan && c->cap <= kSmallRebuildN) {  // whole rebuild by one workgroup (off: slower)
+        launch(c, "k_rebuild_small", k_rebuild_small, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const int *)c->flags.get(), c->count.get(), d.start, c->grid.ncells,
                (const int *)c->cellid.get(), c->perm.get(), reorder_args(src, s.id, d, c->tmp.src_of));
         return;
     }
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
-        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_blocks_particles,
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(),
                (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr);
     } else {
         int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
         launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
                (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
-        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_blocks_particles,
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(), (const int *)tile_sum,
                tile_off, c->n_tiles, (const int *)nullptr);
         launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
@@ -378,13 +416,27 @@ void ctx_alloc(sphx_ctx *c, int cap)
     DevBuf<double> *dbl[] = {&c->xn, &c->yn, &c->vxn, &c->vyn, &c->drhon, &c->rho, &c->Vol, &c->rhoh, &c->ph, &c->b11,
                              &c->b12, &c->b21, &c->b22, &c->fpx, &c->fpy, &c->ffx, &c->ffy, &c->rho_out, &c->p_out};
     for (auto *b : dbl) { b->alloc(cap); b->zero(c->stream); }
-    c->vpart.alloc(c->n_blocks_particles);
+    // tiling of the neighbour passes: tile_cells (params.reserved) 0 = auto (tiled from 200 k particles),
+    // < 0 = never, > 0 = that many cells per tile
+    {
+        const int want = c->prm.reserved;
+        const double rows_fluid = std::max(1.0, c->prm.DH / (2.0 * c->prm.h));
+        const double per_cell = std::max(1.0, (double)c->nf / ((double)std::floor(c->prm.DL / (2.0 * c->prm.h)) * rows_fluid));
+        const int hcap = 512;
+        int ct = want > 0 ? want : (int)std::floor(hcap / (3.0 * 1.4 * per_cell)) - 2;
+        ct = std::max(1, std::min(ct, g.ncy));
+        c->tiled = want > 0 || (want == 0 && cap >= 200000);
+        c->tcfg = TileCfg{ct, (g.ncy + ct - 1) / ct, hcap};
+    }
+    c->n_vpart = c->tiled ? g.ncx * c->tcfg.nseg : c->n_blocks_particles;
+    c->vpart.alloc(c->n_vpart);
     c->vpart.zero(c->stream);
     c->cellid.alloc(cap); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(cap); c->src_of.alloc(cap);
     c->count.zero(c->stream);
     const int nl_cap = nl_cap_for(c->lpp);
     const size_t stride = (size_t)c->n_blocks_particles * kBlock;  // one list column per launched lane
-    c->nl_idx.alloc(stride * nl_cap);
+    if (c->tiled) c->nl16.alloc(stride * nl_cap);
+    else c->nl_idx.alloc(stride * nl_cap);
     c->nl_cnt.alloc(stride);
     c->nl_cnt.zero(c->stream);
     c->flags.alloc(1);
@@ -527,6 +579,7 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     c->phys = make_phys(prm);
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
+    if (prm->lanes_per_particle <= 0 && (prm->reserved > 0 || (prm->reserved == 0 && nf >= 200000))) c->lpp = std::max(c->lpp, 2);
     check_lpp(c->lpp);
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 16;
     if (c->spg & 1) c->spg += 1;
@@ -1061,7 +1114,7 @@ SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *se
     const int q = c->cur;
     const Clock *clk = c->clock.get();
     launch_physics_any(c, q, 0);
-    launch(c, "k_vmax_reduce", k_vmax_reduce, dim3(1), dim3(kScanBlock), clk, q, c->n_blocks_particles,
+    launch(c, "k_vmax_reduce", k_vmax_reduce, dim3(1), dim3(kScanBlock), clk, q, c->n_vpart,
            (const double *)c->vpart.get(), vmax_local_dev);
     SlabPack p = c->pack;
     p.send_l = send_left_dev;
