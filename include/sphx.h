@@ -144,8 +144,8 @@ typedef struct sphx_params {
     int32_t sort_interval;  /* kept for signature parity; the device re-sorts by cell every step     */
     int32_t lanes_per_particle; /* 0 = auto; 1,2,4,8,16,32: lanes cooperating on one neighbour ring */
     int32_t steps_per_graph;    /* 0 = auto; steps captured per hipGraph replay (even)               */
-    int32_t reserved;           /* tile_cells: 0 = auto (LDS-tiled passes from 200 k particles), <0 = never,
-                                   >0 = cells per LDS tile (forces the tiled kernels)                  */
+    int32_t reserved;           /* tile_cells: >0 = experimental LDS-tiled neighbour passes with that many
+                                   cells per tile; <=0 = list-walking passes (default)                 */
 } sphx_params;
 
 typedef struct sphx_status {

@@ -417,8 +417,9 @@ void ctx_alloc(sphx_ctx *c, int cap)
     DevBuf<double> *dbl[] = {&c->xn, &c->yn, &c->vxn, &c->vyn, &c->drhon, &c->rho, &c->Vol, &c->rhoh, &c->ph, &c->b11,
                              &c->b12, &c->b21, &c->b22, &c->fpx, &c->fpy, &c->ffx, &c->ffy, &c->rho_out, &c->p_out};
     for (auto *b : dbl) { b->alloc(cap); b->zero(c->stream); }
-    // tiling of the neighbour passes: tile_cells (params.reserved) 0 = auto (tiled from 200 k particles),
-    // < 0 = never, > 0 = that many cells per tile
+    // tiling of the neighbour passes: tile_cells (params.reserved) > 0 = LDS-tiled kernels with that many cells
+    // per tile (experimental: measured 1.4-2x SLOWER than the list-walking kernels at 0.5-6 M particles, see
+    // DESIGN.md); <= 0 = list-walking kernels
     {
         const int want = c->prm.reserved;
         const double rows_fluid = std::max(1.0, c->prm.DH / (2.0 * c->prm.h));
@@ -426,7 +427,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
         const int hcap = 512;
         int ct = want > 0 ? want : (int)std::floor(hcap / (3.0 * 1.4 * per_cell)) - 2;
         ct = std::max(1, std::min(ct, g.ncy));
-        c->tiled = want > 0 || (want == 0 && cap >= 200000);
+        c->tiled = want > 0;
         c->tcfg = TileCfg{ct, (g.ncy + ct - 1) / ct, hcap};
     }
     c->n_vpart = c->tiled ? g.ncx * c->tcfg.nseg : c->n_blocks_particles;
@@ -580,7 +581,7 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     c->phys = make_phys(prm);
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
-    if (prm->lanes_per_particle <= 0 && (prm->reserved > 0 || (prm->reserved == 0 && nf >= 200000))) c->lpp = std::max(c->lpp, 2);
+    if (prm->lanes_per_particle <= 0 && prm->reserved > 0) c->lpp = std::max(c->lpp, 2);
     check_lpp(c->lpp);
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 16;
     if (c->spg & 1) c->spg += 1;
