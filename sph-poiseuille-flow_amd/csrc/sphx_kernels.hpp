@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
             const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
             const double r2 = dx * dx + dy * dy;
             if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                s_in += spline_W(ph.kc, sqrt(r2));
+                s_in += spline_W(ph.kc, r2 * rsqrt(r2));
                 if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = k;
                 ++cnt;
             }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
                 const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
                 const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, sqrt(r2)) * w.Vol[k];
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * w.Vol[k];
             });
         }
         if (cnt > t.nl_cap) { atomicOr(t.flags, 1); cnt = t.nl_cap; }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
     if (active) {
         const double xi = s.x[i], yi = s.y[i];
         auto term = [&](double dx, double dy, double Volj) {
-            const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
             const double fxj = spline_dW(ph.kc, r) * Volj;
             a11 -= dx * (fxj * ex);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         for (int m = 0; m < nn; ++m) {
             const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
             const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
-            const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
             const double dW = spline_dW(ph.kc, r);
             const double Volj = t.Vol[k];
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
                 const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
                 const double r2 = dx * dx + dy * dy;
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                    const double r = sqrt(r2), inv_r = 1.0 / r;
+                    const double inv_r = rsqrt(r2), r = r2 * inv_r;
                     const double ex = dx * inv_r, ey = dy * inv_r;
                     const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
                     const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
             const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
             const double r2 = dx * dx + dy * dy;
             if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                const double r = sqrt(r2), inv_r = 1.0 / r;
+                const double inv_r = rsqrt(r2), r = r2 * inv_r;
                 const double ex = dx * inv_r, ey = dy * inv_r;
                 const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
                 const double face = -(acx * ex + acy * ey);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
         for (int m = 0; m < nn; ++m) {
             const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
             const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
-            const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
             const double u_jump = (vxi - t.vxn[k]) * ex + (vyi - t.vyn[k]) * ey;
             rate += u_jump * spline_dW(ph.kc, r) * t.Vol[k];
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
                 const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
                 const double r2 = dx * dx + dy * dy;
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                    const double r = sqrt(r2), inv_r = 1.0 / r;
+                    const double inv_r = rsqrt(r2), r = r2 * inv_r;
                     const double ex = dx * inv_r, ey = dy * inv_r;
                     const double vjx = 2.0 * w.vx[k] - vxi, vjy = 2.0 * w.vy[k] - vyi;
                     const double jump = (vxi - vjx) * ex + (vyi - vjy) * ey;

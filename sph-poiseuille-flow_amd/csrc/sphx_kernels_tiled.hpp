@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_density_t(const Clock *clk, int q, G
                     const double dx = min_image(g, xi - lx[k]), dy = yi - ly[k];
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                        s_in += spline_W(ph.kc, sqrt(r2));
+                        s_in += spline_W(ph.kc, r2 * rsqrt(r2));
                         if (cnt < t.nl_cap) nl16[(size_t)cnt * t.nl_stride + lane] = (unsigned short)k;
                         ++cnt;
                     }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void k_density_t(const Clock *clk, int q, G
                 sweep<LPP>(g, w.start, tl.cx, cy, sub, [&](int k) {
                     const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
                     const double r2 = dx * dx + dy * dy;
-                    if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, sqrt(r2)) * w.Vol[k];
+                    if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * w.Vol[k];
                 });
             }
             if (cnt > t.nl_cap) { atomicOr(t.flags, 1); cnt = t.nl_cap; }
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc_t(const Clock *clk, int q, Grid 
         if (active) {
             const double xi = lx[tl.own + pp], yi = ly[tl.own + pp];
             auto term = [&](double dx, double dy, double Volj) {
-                const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+                const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
                 const double ex = dx * inv_r, ey = dy * inv_r;
                 const double fxj = spline_dW(ph.kc, r) * Volj;
                 a11 -= dx * (fxj * ex);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void k_forces_t(const Clock *clk, int q, Gr
             for (int m = 0; m < nn; ++m) {
                 const int k = nl16[(size_t)m * t.nl_stride + lane];
                 const double dx = min_image(g, xi - lx[k]), dy = yi - ly[k];
-                const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+                const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
                 const double ex = dx * inv_r, ey = dy * inv_r;
                 const double dW = spline_dW(ph.kc, r);
                 const double Volj = lV[k];
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_forces_t(const Clock *clk, int q, Gr
                     const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                        const double r = sqrt(r2), inv_r = 1.0 / r;
+                        const double inv_r = rsqrt(r2), r = r2 * inv_r;
                         const double ex = dx * inv_r, ey = dy * inv_r;
                         const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
                         const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_forces_t(const Clock *clk, int q, Gr
                 const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
                 const double r2 = dx * dx + dy * dy;
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                    const double r = sqrt(r2), inv_r = 1.0 / r;
+                    const double inv_r = rsqrt(r2), r = r2 * inv_r;
                     const double ex = dx * inv_r, ey = dy * inv_r;
                     const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
                     const double face = -(acx * ex + acy * ey);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity_t(const Clock *clk, int q
                 for (int m = 0; m < nn; ++m) {
                     const int k = nl16[(size_t)m * t.nl_stride + lane];
                     const double dx = min_image(g, xi - lx[k]), dy = yi - ly[k];
-                    const double r = sqrt(dx * dx + dy * dy), inv_r = 1.0 / r;
+                    const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
                     const double ex = dx * inv_r, ey = dy * inv_r;
                     const double u_jump = (vxi - lvx[k]) * ex + (vyi - lvy[k]) * ey;
                     rate += u_jump * spline_dW(ph.kc, r) * lV[k];
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity_t(const Clock *clk, int q
                         const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
                         const double r2 = dx * dx + dy * dy;
                         if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                            const double r = sqrt(r2), inv_r = 1.0 / r;
+                            const double inv_r = rsqrt(r2), r = r2 * inv_r;
                             const double ex = dx * inv_r, ey = dy * inv_r;
                             const double vjx = 2.0 * w.vx[k] - vxi, vjy = 2.0 * w.vy[k] - vyi;
                             const double jump = (vxi - vjx) * ex + (vyi - vjy) * ey;
