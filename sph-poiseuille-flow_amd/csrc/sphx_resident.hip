@@ -69,6 +69,7 @@ struct sphx_ctx {
     TileCfg tcfg{};
     int n_vpart = 0;             // entries of vpart the clock kernel reduces
     DevBuf<unsigned short> nl16;
+    bool fused_scatter = true;   // small grids: clock+scan+scatter in one launch
     bool fused_rebuild = false;  // measured slower than three launches at 5 k particles (48 us vs 21 us)
     int n_tiles = 0;
     hipStream_t stream = nullptr;
@@ -78,7 +79,7 @@ struct sphx_ctx {
     DevBuf<double> fx_[2], fy_[2], fvx_[2], fvy_[2], fdrho_[2], fmass_[2];
     DevBuf<int> fid_[2], fstart_[2];
     DevBuf<double> xn, yn, vxn, vyn, drhon, rho, Vol, rhoh, ph, b11, b12, b21, b22, fpx, fpy, ffx, ffy, rho_out, p_out, vpart;
-    DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, flags, tile;
+    DevBuf<int> cellid, count, cursor, perm, src_of, nl_idx, nl_cnt, flags, tile;
     DevBuf<double> wx, wy, wVol, wvx, wvy;
     DevBuf<int> wid, wstart, wrow_any;
     DevBuf<Clock> clock;
@@ -243,7 +244,7 @@ void launch_scatter_reorder(sphx_ctx *c, int q, const double *const src[6], cons
     launch(c, "k_scatter", k_scatter, g1, bp, clk, q, 0, (const int *)c->cellid.get(), c->count.get(), (const int *)d.start,
            c->perm.get());
     launch(c, "k_reorder", k_reorder, g1, bp, clk, q, 0, (const int *)c->cellid.get(), (const int *)d.start,
-           (const int *)c->perm.get(), reorder_args(src, id_src, d, src_of));
+           (const int *)c->perm.get(), reorder_args(src, id_src, d, src_of), (int *)nullptr, (int *)nullptr, 0);
 }
 
 // one single-GPU step slot of parity q
@@ -258,6 +259,16 @@ void launch_step(sphx_ctx *c, int q)
         launch(c, "k_rebuild_small", k_rebuild_small, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const int *)c->flags.get(), c->count.get(), d.start, c->grid.ncells,
                (const int *)c->cellid.get(), c->perm.get(), reorder_args(src, s.id, d, c->tmp.src_of));
+        return;
+    }
+    if (!c->big_scan && c->fused_scatter) {  // clock + scan + scatter in one launch, reorder resets the histogram
+        launch(c, "k_clock_scan_scatter", k_clock_scan_scatter, dim3(div_up((size_t)c->cap, kScanBlock)), dim3(kScanBlock),
+               clk, q, c->phys, c->n_vpart, (const double *)c->vpart.get(), (const int *)c->flags.get(),
+               (const int *)c->count.get(), c->cursor.get(), d.start, c->grid.ncells, (const int *)c->cellid.get(),
+               c->perm.get());
+        launch(c, "k_reorder", k_reorder, dim3(c->n_blocks_flat), dim3(kBlock), (const Clock *)clk, q, 0,
+               (const int *)c->cellid.get(), (const int *)d.start, (const int *)c->perm.get(),
+               reorder_args(src, s.id, d, c->tmp.src_of), c->count.get(), c->cursor.get(), c->grid.ncells);
         return;
     }
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
@@ -386,7 +397,7 @@ void initial_sort(sphx_ctx *c, const Grid &g, int n, const double *x, const doub
     hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
                        (const int *)cellid, count, (const int *)start, perm);
     hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
-                       (const int *)cellid, (const int *)start, (const int *)perm, ra);
+                       (const int *)cellid, (const int *)start, (const int *)perm, ra, (int *)nullptr, (int *)nullptr, 0);
     SPHX_HIP(hipGetLastError());
 }
 
@@ -435,6 +446,8 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->vpart.zero(c->stream);
     c->cellid.alloc(cap); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(cap); c->src_of.alloc(cap);
     c->count.zero(c->stream);
+    c->cursor.alloc((size_t)g.ncells + 1);
+    c->cursor.zero(c->stream);
     const int nl_cap = nl_cap_for(c->lpp);
     const size_t stride = (size_t)c->n_blocks_particles * kBlock;  // one list column per launched lane
     if (c->tiled) c->nl16.alloc(stride * nl_cap);
