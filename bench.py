@@ -81,6 +81,65 @@ def cpu_baseline(cfg, geo, prm, parts, budget_s=20.0):
                        f"{st['stats']['seconds_physics']:.1f}s OpenMP pair loops, {threads} threads)")
 
 
+def pmc_traffic(name, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
+    2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of MI355X_MICROARCH.md applied); None if not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)[name][kernel.replace("_t", "")]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=0, tile=0, lattice=False):
+    """Time `steps` resident steps of one workload; returns (result dict, prm, parts, pos, vel)."""
+    import torch
+    prm = cfg.params_from_values(end_time=1e9, **kw)
+    parts = geo.init_particles(prm)
+    nf, nw, nt = parts["n_fluid"], parts["n_wall"], parts["n_total"]
+    if lattice:
+        pos, vel, start = parts["pos"], parts["vel"], "lattice at rest"
+    else:
+        pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
+        start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
+    ctx = capi.Context(prm, nf, nt, pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9,
+                       lanes_per_particle=lpp, steps_per_graph=spg, tile_cells=tile)
+    info, tuning = ctx.info(), ctx.tuning()
+    if warmup > 0:
+        ctx.enqueue_steps(warmup)  # untimed: includes graph capture/instantiation
+    st0 = ctx.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.enqueue_steps(steps)
+    st1 = ctx.sync()
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    assert st1["step"] - st0["step"] == steps, (st0, st1)
+    roof, kernels = None, {}
+    if profile_steps > 0:  # per-kernel device time, live: HIP event pair around every launch on the ctx stream
+        ctx.profile_enable(True)
+        ctx.enqueue_steps(profile_steps)
+        ctx.sync()
+        kernels = ctx.profile_read()
+        ctx.profile_enable(False)
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+            ms = kernels[dom]["avg_ms"]
+            alg = BYTES_PER_FLUID.get(dom, 0) * nf + BYTES_PER_WALL.get(dom, 0) * nw
+            achieved = alg / (ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(name, dom), launch_ms=ms, algorithmic_bytes=alg,
+                        step_achieved=(STEP_BYTES_FLUID * nf + STEP_BYTES_WALL * nw) * steps / seconds / 1e9)
+    ctx.close()
+    res = dict(value=nt * steps / seconds, ms_per_step=1e3 * seconds / steps, seconds=seconds, roofline=roof,
+               kernels_ms={k: round(v["avg_ms"], 6) for k, v in kernels.items()},
+               workload=f"{name}: dp={prm.dp}, DL={prm.DL}, DH={prm.DH}, n_fluid={nf}, n_wall={nw}, n_total={nt}, "
+                        f"c_f={prm.c_f}, transport_coeff={prm.transport_coeff}; start={start}",
+               cells=[info["n_cell_x"], info["n_cell_y"]], tuning=tuning,
+               sim={"t": st1["t"], "dt": st1["dt_last"], "vmax": st1["vmax"]})
+    return res, prm, parts, pos, vel
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +151,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="cells per LDS tile (0 = auto, -1 = list-walking kernels only)")
     ap.add_argument("--profile-steps", type=int, default=200, help="eager steps timed per kernel with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the C4/C5 side measurements of the default run")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--lattice", action="store_true", help="pristine lattice start instead of the developed state")
     args = ap.parse_args()
@@ -118,63 +178,29 @@ def main():
         return slab.bench_main(args, rank, world, local_rank)
 
     name, kw = parse_workload(args.workload or "C2")
-    prm = cfg.params_from_values(end_time=1e9, **kw)
-    parts = geo.init_particles(prm)
-    nf, nw, nt = parts["n_fluid"], parts["n_wall"], parts["n_total"]
-    if args.lattice:
-        pos, vel, start = parts["pos"], parts["vel"], "lattice at rest"
-    else:
-        pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
-        start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
-
-    ctx = capi.Context(prm, nf, nt, pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9,
-                       lanes_per_particle=args.lpp, steps_per_graph=args.spg, tile_cells=args.tile)
-    info = ctx.info()
-    tuning = ctx.tuning()
-    # warm-up (untimed): includes graph capture/instantiation
-    if args.warmup > 0:
-        ctx.enqueue_steps(args.warmup)
-    st0 = ctx.sync()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ctx.enqueue_steps(args.steps)
-    st1 = ctx.sync()
-    torch.cuda.synchronize()
-    seconds = time.perf_counter() - t0
-    assert st1["step"] - st0["step"] == args.steps, (st0, st1)
-    value = nt * args.steps / seconds
-
-    # per-kernel device time, live, with HIP events on the context's stream (eager launches)
-    roof = None
-    kernels = {}
-    if args.profile_steps > 0:
-        ctx.profile_enable(True)
-        ctx.enqueue_steps(args.profile_steps)  # exact slot count: replays of the event-instrumented graph
-        ctx.sync()
-        kernels = ctx.profile_read()
-        ctx.profile_enable(False)
-        if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-            ms = kernels[dom]["avg_ms"]
-            alg = BYTES_PER_FLUID.get(dom, 0) * nf + BYTES_PER_WALL.get(dom, 0) * nw
-            achieved = alg / (ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, launch_ms=ms, algorithmic_bytes=alg,
-                        step_achieved=(STEP_BYTES_FLUID * nf + STEP_BYTES_WALL * nw) * args.steps / seconds / 1e9)
-    ctx.close()
-
+    r, prm, parts, pos, vel = run_case(capi, cfg, geo, name, kw, args.steps, args.warmup, args.profile_steps, args.lpp,
+                                       args.spg, args.tile, args.lattice)
+    value = r["value"]
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * seconds / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{name}: dp={prm.dp}, DL={prm.DL}, DH={prm.DH}, n_fluid={nf}, n_wall={nw}, "
-                               f"n_total={nt}, c_f={prm.c_f}, transport_coeff={prm.transport_coeff}; start={start}",
-                   "cells": [info["n_cell_x"], info["n_cell_y"]], "lanes_per_particle": tuning["lanes_per_particle"], "steps_per_graph": tuning["steps_per_graph"],
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": r["workload"], "cells": r["cells"],
+                   "lanes_per_particle": r["tuning"]["lanes_per_particle"],
+                   "steps_per_graph": r["tuning"]["steps_per_graph"],
                    "parallelism": "1 GPU, device-resident loop, hipGraph replay"},
-        "roofline": roof,
-        "kernels_ms": {k: round(v["avg_ms"], 6) for k, v in kernels.items()},
-        "sim": {"t": st1["t"], "dt": st1["dt_last"], "vmax": st1["vmax"]},
+        "roofline": r["roofline"], "kernels_ms": r["kernels_ms"], "sim": r["sim"],
     }
+    if not args.no_aux and args.workload is None:
+        # the headline case is launch-latency bound (5 760 particles); report the same loop at 0.5 M and 6.1 M
+        # particles as well so the kernels' throughput regime is on record (not the headline value)
+        out["aux"] = {}
+        for aux_name, aux_steps in (("C4", 200), ("C5", 30)):
+            try:
+                a = run_case(capi, cfg, geo, aux_name, dict(WORKLOADS[aux_name]), aux_steps, 16, 16)[0]
+                out["aux"][aux_name] = {k: a[k] for k in ("value", "ms_per_step", "roofline", "kernels_ms", "workload", "tuning")}
+            except Exception as e:  # never let the side measurements break the headline line
+                out["aux"][aux_name] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, geo, prm, dict(parts, pos=pos, vel=vel), args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -69,7 +69,7 @@ struct sphx_ctx {
     TileCfg tcfg{};
     int n_vpart = 0;             // entries of vpart the clock kernel reduces
     DevBuf<unsigned short> nl16;
-    bool fused_scatter = true;   // small grids: clock+scan+scatter in one launch
+    bool fused_scatter = false;  // small grids: clock+scan+scatter in one launch (measured: 49.0 vs 48.0 us/step at C2, no gain)
     bool fused_rebuild = false;  // measured slower than three launches at 5 k particles (48 us vs 21 us)
     int n_tiles = 0;
     hipStream_t stream = nullptr;
