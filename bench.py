@@ -124,11 +124,16 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
         ctx.profile_enable(False)
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-            ms = kernels[dom]["avg_ms"]
+            ms_eager = kernels[dom]["avg_ms"]
+            try:  # the dominant kernel alone, back-to-back in a replayed graph: the regime of the timed region
+                ms = ctx.time_kernel(dom, reps=max(20, min(400, int(0.05 / max(ms_eager * 1e-3, 1e-7)))))
+            except capi.SphxError:
+                ms = ms_eager
             alg = BYTES_PER_FLUID.get(dom, 0) * nf + BYTES_PER_WALL.get(dom, 0) * nw
             achieved = alg / (ms * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(name, dom), launch_ms=ms, algorithmic_bytes=alg,
+                        frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(name, dom), launch_ms=ms, launch_ms_eager=ms_eager,
+                        algorithmic_bytes=alg,
                         step_achieved=(STEP_BYTES_FLUID * nf + STEP_BYTES_WALL * nw) * steps / seconds / 1e9)
     ctx.close()
     res = dict(value=nt * steps / seconds, ms_per_step=1e3 * seconds / steps, seconds=seconds, roofline=roof,

@@ -196,6 +196,10 @@ int sphx_ctx_profile_enable(sphx_ctx *ctx, int on);
 int sphx_ctx_profile_read(sphx_ctx *ctx, int capacity, const char **names, double *avg_ms,
                           int64_t *launches, int *n_kernels);
 
+/* Average duration (ms) of ONE neighbour-pass kernel ("k_density", "k_kgc", "k_forces", "k_continuity") in
+ * the hipGraph-replay regime: `reps` back-to-back launches between two HIP events; state is left unchanged. */
+int sphx_ctx_time_kernel(sphx_ctx *ctx, const char *name, int reps, double *avg_ms);
+
 /* The launch shape the context chose (lanes cooperating per particle, steps per hipGraph replay). */
 int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph);
 

@@ -48,7 +48,7 @@ EXPORTS = [
     "sphx_integration_verlet", "sphx_advance_shell_step", "sphx_wall_shear_monitor",
     "sphx_ctx_create", "sphx_ctx_destroy", "sphx_ctx_advance", "sphx_ctx_enqueue_steps", "sphx_ctx_sync",
     "sphx_ctx_download", "sphx_ctx_monitor", "sphx_ctx_neighbor_list", "sphx_ctx_profile_enable",
-    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning",
+    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_time_kernel",
     "sphx_slab_create", "sphx_slab_layout", "sphx_slab_local_vmax", "sphx_slab_prepare", "sphx_slab_compute",
     "sphx_slab_finish", "sphx_slab_sync", "sphx_slab_snapshot",
 ]
@@ -177,6 +177,11 @@ class Context:
         a, b = C.c_int(0), C.c_int(0)
         check(lib().sphx_ctx_tuning(self._h, C.byref(a), C.byref(b)))
         return dict(lanes_per_particle=a.value, steps_per_graph=b.value)
+
+    def time_kernel(self, name, reps=200) -> float:
+        ms = C.c_double(0.0)
+        check(lib().sphx_ctx_time_kernel(self._h, name.encode(), C.c_int(reps), C.byref(ms)))
+        return ms.value
 
     def profile_enable(self, on=True):
         check(lib().sphx_ctx_profile_enable(self._h, C.c_int(1 if on else 0)))

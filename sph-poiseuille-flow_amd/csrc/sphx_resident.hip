@@ -179,8 +179,9 @@ ReorderArgs reorder_args(const double *const src[6], const int *id_src, const Fl
     return ra;
 }
 
+// only: 0 = all four neighbour passes, 1..4 = just density / kgc / forces / continuity (kernel timing)
 template <int LPP>
-void launch_physics(sphx_ctx *c, int q, int do_hist)
+void launch_physics(sphx_ctx *c, int q, int do_hist, int only = 0)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
@@ -190,31 +191,36 @@ void launch_physics(sphx_ctx *c, int q, int do_hist)
         const dim3 gt(c->grid.ncx * tc.nseg);
         const size_t H = (size_t)tc.hcap * sizeof(double);
         unsigned short *nl = c->nl16.get();
-        launch_s(c, "k_density_t", k_density_t<LPP>, gt, bp, 2 * H + 3 * (size_t)(tc.ct + 4) * sizeof(int), clk, q, c->grid,
-                 c->phys, s, c->tmp, c->walls, tc, nl);
-        launch_s(c, "k_kgc_t", k_kgc_t<LPP>, gt, bp, 3 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls, tc,
-                 (const unsigned short *)nl);
-        launch_s(c, "k_forces_t", k_forces_t<LPP>, gt, bp, 11 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls, tc,
-                 (const unsigned short *)nl);
-        launch_s(c, "k_continuity_t", k_continuity_t<LPP>, gt, bp, 5 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls,
-                 do_hist, tc, (const unsigned short *)nl);
+        if (!only || only == 1)
+            launch_s(c, "k_density_t", k_density_t<LPP>, gt, bp, 2 * H + 3 * (size_t)(tc.ct + 4) * sizeof(int), clk, q,
+                     c->grid, c->phys, s, c->tmp, c->walls, tc, nl);
+        if (!only || only == 2)
+            launch_s(c, "k_kgc_t", k_kgc_t<LPP>, gt, bp, 3 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls, tc,
+                     (const unsigned short *)nl);
+        if (!only || only == 3)
+            launch_s(c, "k_forces_t", k_forces_t<LPP>, gt, bp, 11 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls, tc,
+                     (const unsigned short *)nl);
+        if (!only || only == 4)
+            launch_s(c, "k_continuity_t", k_continuity_t<LPP>, gt, bp, 5 * H, clk, q, c->grid, c->phys, s, c->tmp,
+                     c->walls, do_hist, tc, (const unsigned short *)nl);
         return;
     }
-    launch(c, "k_density", k_density<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
-    launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
-    launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
-    launch(c, "k_continuity", k_continuity<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls, do_hist);
+    if (!only || only == 1) launch(c, "k_density", k_density<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
+    if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
+    if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
+    if (!only || only == 4)
+        launch(c, "k_continuity", k_continuity<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls, do_hist);
 }
 
-void launch_physics_any(sphx_ctx *c, int q, int do_hist)
+void launch_physics_any(sphx_ctx *c, int q, int do_hist, int only = 0)
 {
     switch (c->lpp) {
-        case 1: launch_physics<1>(c, q, do_hist); break;
-        case 2: launch_physics<2>(c, q, do_hist); break;
-        case 4: launch_physics<4>(c, q, do_hist); break;
-        case 8: launch_physics<8>(c, q, do_hist); break;
-        case 16: launch_physics<16>(c, q, do_hist); break;
-        case 32: launch_physics<32>(c, q, do_hist); break;
+        case 1: launch_physics<1>(c, q, do_hist, only); break;
+        case 2: launch_physics<2>(c, q, do_hist, only); break;
+        case 4: launch_physics<4>(c, q, do_hist, only); break;
+        case 8: launch_physics<8>(c, q, do_hist, only); break;
+        case 16: launch_physics<16>(c, q, do_hist, only); break;
+        case 32: launch_physics<32>(c, q, do_hist, only); break;
         default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
     }
 }
@@ -1209,6 +1215,64 @@ SPHX_EXPORT int sphx_slab_snapshot(sphx_ctx *c, int capacity, int *n, double *x,
     SPHX_HIP(hipStreamSynchronize(s));
     if (owned)
         for (int i = 0; i < m; ++i) owned[i] = (hx[i] >= c->grid.own_lo && hx[i] < c->grid.own_hi) ? 1 : 0;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+// Average duration of one neighbour-pass kernel in the hipGraph-replay regime: `reps` back-to-back launches of
+// that kernel alone are captured in a graph and replayed between two HIP events on the context's stream.  The
+// passes only write per-step temporaries (continuity runs without its histogram), so the state is unchanged.
+// This is the same quantity rocprofv3's kernel trace reports for the timed region (start of a dispatch to its
+// end, dispatch gap included); the eager event-pair numbers of sphx_ctx_profile_* carry extra launch overhead
+// at small particle counts.
+SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, double *avg_ms)
+{
+    SPHX_TRY
+    require(c != nullptr && name != nullptr && avg_ms != nullptr && reps > 0, "SPHX:Ctx:null", "bad arguments");
+    require(!c->is_slab, "SPHX:Ctx:slab", "not available on a slab context");
+    const std::string n(name);
+    int only = 0;
+    if (n == "k_density" || n == "k_density_t") only = 1;
+    else if (n == "k_kgc" || n == "k_kgc_t") only = 2;
+    else if (n == "k_forces" || n == "k_forces_t") only = 3;
+    else if (n == "k_continuity" || n == "k_continuity_t") only = 4;
+    require(only != 0, "SPHX:Ctx:kernel", "time_kernel knows k_density, k_kgc, k_forces, k_continuity");
+    read_clock(c);
+    const bool prof = c->profiling;
+    c->profiling = false;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t e = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    try {
+        // arm run[cur] so the kernels execute; no step slot follows, so the clock does not advance
+        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end, (long long)1,
+                           c->cur, (const double *)nullptr);
+        launch_physics_any(c, c->cur, 0, 0);  // make every temporary the timed kernel reads valid
+        SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, 0, only);
+        SPHX_HIP(hipStreamEndCapture(c->stream, &g));
+        SPHX_HIP(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+        SPHX_HIP(hipGraphLaunch(e, c->stream));  // warm
+        SPHX_HIP(hipEventCreate(&a));
+        SPHX_HIP(hipEventCreate(&b));
+        SPHX_HIP(hipEventRecord(a, c->stream));
+        SPHX_HIP(hipGraphLaunch(e, c->stream));
+        SPHX_HIP(hipEventRecord(b, c->stream));
+        SPHX_HIP(hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        SPHX_HIP(hipEventElapsedTime(&ms, a, b));
+        *avg_ms = (double)ms / reps;
+    } catch (...) {
+        c->profiling = prof;
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        if (e) (void)hipGraphExecDestroy(e);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+    }
+    c->profiling = prof;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipGraphExecDestroy(e); (void)hipGraphDestroy(g);
     return SPHX_OK;
     SPHX_CATCH
 }

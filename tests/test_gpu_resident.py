@@ -105,3 +105,28 @@ def test_ctx_neighbor_list_matches_oracle(case, capi, oracle):
     a, b = canon_pairs(nb), canon_pairs(ref)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert_close(a[4], b[4], rtol=1e-13, atol=1e-15 * prm.DL, name="r")
+
+
+def test_time_kernel_leaves_state_untouched(case, capi):
+    """sphx_ctx_time_kernel replays one neighbour pass in a graph; it may only touch per-step temporaries."""
+    prm, parts, lpp = case
+    with _ctx(capi, prm, parts, lpp, t_end=1e9) as ctx:
+        ctx.advance(1e9, max_steps=3)
+        before = ctx.download(fields=("pos", "vel", "drho_dt"))
+        for name in ("k_density", "k_kgc", "k_forces", "k_continuity"):
+            assert ctx.time_kernel(name, reps=8) > 0.0
+        after = ctx.download(fields=("pos", "vel", "drho_dt"))
+        st = ctx.advance(1e9, max_steps=2)
+        assert st["step"] == 5
+    for k in before:
+        assert np.array_equal(before[k], after[k]), k
+    with _ctx(capi, prm, parts, lpp, t_end=1e9) as ref:
+        ref.advance(1e9, max_steps=5)
+        want = ref.download(fields=("pos", "vel", "drho_dt"))
+    with _ctx(capi, prm, parts, lpp, t_end=1e9) as ctx:
+        ctx.advance(1e9, max_steps=3)
+        ctx.time_kernel("k_forces", reps=4)
+        ctx.advance(1e9, max_steps=2)
+        got = ctx.download(fields=("pos", "vel", "drho_dt"))
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k
