@@ -1,6 +1,6 @@
 // sphx_kernels_tiled.hpp -- LDS-tiled variants of the four neighbour passes (large particle counts).
 //
-// PMC profile of the list-walking kernels at 6 M particles (profiles/r01_pmc_c5_v2_summary.txt): the
+// PMC profile of the list-walking kernels at 6 M particles (profiles/r01_pmc_c5_before_xcd_remap_summary.txt): the
 // texture-address unit is busy 83-87 % of the kernel, VALU 22 % -- every neighbour costs up to 13
 // scattered 8-byte gathers through L1.  Here a workgroup owns a TILE = up to CT consecutive cells of one
 // cell column (cells are column-major, so the tile's particles and each of its three halo column
