@@ -651,58 +651,6 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int
     perm[start_next[c] + k] = i;
 }
 
-// Small grids (<= kBigScanCells cells): clock update, cell scan and scatter in ONE launch.  Every
-// workgroup scans the histogram into LDS for itself (a few thousand cells), workgroup 0 also publishes the
-// scan and advances the clock; slots inside a cell are handed out through a separate cursor array so the
-// histogram stays readable for workgroups that start late.  k_reorder zeroes both arrays afterwards.
-__global__ __launch_bounds__(kScanBlock) void k_clock_scan_scatter(Clock *clk, int q, Phys ph, int n_vpart,
-                                                                   const double *vpart, const int *flags,
-                                                                   const int *count, int *cursor, int *start_next,
-                                                                   int ncells, const int *cellid, int *perm)
-{
-    if (!clk->run[q]) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) clk->run[1 - q] = 0;
-        return;
-    }
-    const int n = clk->n;
-    __shared__ int s_start[kBigScanCells + 1];
-    scan_counts(count, s_start, ncells);
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c <= ncells; c += kScanBlock) start_next[c] = s_start[c];
-        double m = 0.0;
-        for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-        __shared__ double s_m[kScanBlock / 64];
-        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
-            Clock c = *clk;
-            c.vmax = sqrt(m);
-            c.t += c.dt;
-            c.dt_last = c.dt;
-            c.step += 1;
-            if (c.steps_left > 0) c.steps_left -= 1;
-            if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
-            if (*flags) c.status = SPHX_ERR_GRID;
-            c.dt = next_dt(c, ph);
-            c.run[1 - q] = loop_continues(c) ? 1 : 0;
-            // only the fields that change are stored: run[q] and n are being read by the other workgroups
-            clk->vmax = c.vmax; clk->t = c.t; clk->dt_last = c.dt_last; clk->step = c.step;
-            clk->steps_left = c.steps_left; clk->status = c.status; clk->run[1 - q] = c.run[1 - q];
-            clk->dt = c.dt;
-        }
-    }
-    const int i = blockIdx.x * kScanBlock + threadIdx.x;
-    if (i < n) {
-        const int c = cellid[i];
-        const int k = atomicAdd(&cursor[c], 1);
-        perm[s_start[c] + k] = i;
-    }
-}
-
 struct ReorderArgs {
     int nd;
     const double *src[8];
@@ -716,14 +664,11 @@ struct ReorderArgs {
 // depend on arrival order, launch shape or domain decomposition) and the gather of every persistent
 // field into the new ordering.
 __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int n_fixed, const int *cellid,
-                                                    const int *start_next, const int *perm, ReorderArgs a,
-                                                    int *zero_a, int *zero_b, int n_zero)
+                                                    const int *start_next, const int *perm, ReorderArgs a)
 {
     if (clk && !clk->run[q]) return;
     const int n = clk ? clk->n : n_fixed;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (zero_a)  // histogram + cursor of the fused scatter: nobody reads them any more in this step
-        for (int c = i; c < n_zero; c += gridDim.x * kBlock) { zero_a[c] = 0; zero_b[c] = 0; }
     if (i >= n) return;
     const int c = cellid[i];
     const int lo = start_next[c], hi = start_next[c + 1];
@@ -740,68 +685,6 @@ __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int
         if (f < a.nd) a.dst[f][dst] = a.src[f][i];
     a.id_dst[dst] = my_id;
     if (a.src_of) a.src_of[dst] = i;
-}
-
-// Small problems (n <= kSmallRebuildN, grid <= kBigScanCells cells): clock update, cell scan, scatter
-// and reorder by ONE workgroup in one launch -- at 5 k particles the three separate launches cost more in
-// dispatch gaps (~4.5 us each) than in work.
-constexpr int kSmallRebuildN = 16384;
-__global__ __launch_bounds__(kScanBlock) void k_rebuild_small(Clock *clk, int q, Phys ph, int n_vpart,
-                                                              const double *vpart, const int *flags, int *count,
-                                                              int *start_next, int ncells, const int *cellid,
-                                                              int *perm, ReorderArgs a)
-{
-    if (!clk->run[q]) {
-        if (threadIdx.x == 0) clk->run[1 - q] = 0;
-        return;
-    }
-    const int n = clk->n;
-    double m = 0.0;
-    for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    __shared__ double s_m[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
-        Clock c = *clk;
-        c.vmax = sqrt(m);
-        c.t += c.dt;
-        c.dt_last = c.dt;
-        c.step += 1;
-        if (c.steps_left > 0) c.steps_left -= 1;
-        if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
-        if (*flags) c.status = SPHX_ERR_GRID;
-        c.dt = next_dt(c, ph);
-        c.run[1 - q] = loop_continues(c) ? 1 : 0;
-        *clk = c;
-    }
-    scan_counts(count, start_next, ncells);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kScanBlock) {
-        const int c = cellid[i];
-        const int k = atomicSub(&count[c], 1) - 1;
-        perm[start_next[c] + k] = i;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kScanBlock) {
-        const int c = cellid[i];
-        const int lo = start_next[c], hi = start_next[c + 1];
-        const int my_id = a.id_src[i];
-        int rank = 0;
-        for (int k = lo; k < hi; ++k) {
-            const int o = perm[k];
-            const int oid = a.id_src[o];
-            rank += (oid < my_id || (oid == my_id && o < i)) ? 1 : 0;
-        }
-        const int dst = lo + rank;
-#pragma unroll
-        for (int f = 0; f < 8; ++f)
-            if (f < a.nd) a.dst[f][dst] = a.src[f][i];
-        a.id_dst[dst] = my_id;
-        if (a.src_of) a.src_of[dst] = i;
-    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_iota(int n, int *a, int base)

@@ -69,8 +69,6 @@ struct sphx_ctx {
     TileCfg tcfg{};
     int n_vpart = 0;             // entries of vpart the clock kernel reduces
     DevBuf<unsigned short> nl16;
-    bool fused_scatter = false;  // small grids: clock+scan+scatter in one launch (measured: 49.0 vs 48.0 us/step at C2, no gain)
-    bool fused_rebuild = false;  // measured slower than three launches at 5 k particles (48 us vs 21 us)
     int n_tiles = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -79,7 +77,7 @@ struct sphx_ctx {
     DevBuf<double> fx_[2], fy_[2], fvx_[2], fvy_[2], fdrho_[2], fmass_[2];
     DevBuf<int> fid_[2], fstart_[2];
     DevBuf<double> xn, yn, vxn, vyn, drhon, rho, Vol, rhoh, ph, b11, b12, b21, b22, fpx, fpy, ffx, ffy, rho_out, p_out, vpart;
-    DevBuf<int> cellid, count, cursor, perm, src_of, nl_idx, nl_cnt, flags, tile;
+    DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, flags, tile;
     DevBuf<double> wx, wy, wVol, wvx, wvy;
     DevBuf<int> wid, wstart, wrow_any;
     DevBuf<Clock> clock;
@@ -250,7 +248,7 @@ void launch_scatter_reorder(sphx_ctx *c, int q, const double *const src[6], cons
     launch(c, "k_scatter", k_scatter, g1, bp, clk, q, 0, (const int *)c->cellid.get(), c->count.get(), (const int *)d.start,
            c->perm.get());
     launch(c, "k_reorder", k_reorder, g1, bp, clk, q, 0, (const int *)c->cellid.get(), (const int *)d.start,
-           (const int *)c->perm.get(), reorder_args(src, id_src, d, src_of), (int *)nullptr, (int *)nullptr, 0);
+           (const int *)c->perm.get(), reorder_args(src, id_src, d, src_of));
 }
 
 // one single-GPU step slot of parity q
@@ -261,22 +259,6 @@ void launch_step(sphx_ctx *c, int q)
     const FluidSet &s = c->set[q];
     const FluidSet &d = c->set[1 - q];
     const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
-    if (c->fused_rebuild && !c->big_scan && c->cap <= kSmallRebuildN) {  // whole rebuild by one workgroup (off: slower)
-        launch(c, "k_rebuild_small", k_rebuild_small, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
-               (const double *)c->vpart.get(), (const int *)c->flags.get(), c->count.get(), d.start, c->grid.ncells,
-               (const int *)c->cellid.get(), c->perm.get(), reorder_args(src, s.id, d, c->tmp.src_of));
-        return;
-    }
-    if (!c->big_scan && c->fused_scatter) {  // clock + scan + scatter in one launch, reorder resets the histogram
-        launch(c, "k_clock_scan_scatter", k_clock_scan_scatter, dim3(div_up((size_t)c->cap, kScanBlock)), dim3(kScanBlock),
-               clk, q, c->phys, c->n_vpart, (const double *)c->vpart.get(), (const int *)c->flags.get(),
-               (const int *)c->count.get(), c->cursor.get(), d.start, c->grid.ncells, (const int *)c->cellid.get(),
-               c->perm.get());
-        launch(c, "k_reorder", k_reorder, dim3(c->n_blocks_flat), dim3(kBlock), (const Clock *)clk, q, 0,
-               (const int *)c->cellid.get(), (const int *)d.start, (const int *)c->perm.get(),
-               reorder_args(src, s.id, d, c->tmp.src_of), c->count.get(), c->cursor.get(), c->grid.ncells);
-        return;
-    }
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(),
@@ -403,7 +385,7 @@ void initial_sort(sphx_ctx *c, const Grid &g, int n, const double *x, const doub
     hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
                        (const int *)cellid, count, (const int *)start, perm);
     hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
-                       (const int *)cellid, (const int *)start, (const int *)perm, ra, (int *)nullptr, (int *)nullptr, 0);
+                       (const int *)cellid, (const int *)start, (const int *)perm, ra);
     SPHX_HIP(hipGetLastError());
 }
 
@@ -452,8 +434,6 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->vpart.zero(c->stream);
     c->cellid.alloc(cap); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(cap); c->src_of.alloc(cap);
     c->count.zero(c->stream);
-    c->cursor.alloc((size_t)g.ncells + 1);
-    c->cursor.zero(c->stream);
     const int nl_cap = nl_cap_for(c->lpp);
     const size_t stride = (size_t)c->n_blocks_particles * kBlock;  // one list column per launched lane
     if (c->tiled) c->nl16.alloc(stride * nl_cap);
