@@ -23,13 +23,21 @@ struct TileCfg {
     int hcap;   // LDS capacity in particles (tile + halo)
 };
 
-struct Tile {
-    int cx, r0, r1, rlo, rhi;  // own rows [r0,r1), halo rows [rlo,rhi]
-    int g0[3], off[3];         // global start and LDS offset of the three halo column segments
+struct Tile {  // scalar members only: a runtime-indexed array here lands in scratch memory
+    int cx, r0, r1, rlo, rhi;   // own rows [r0,r1), halo rows [rlo,rhi]
+    int g0a, g0b, g0c;          // global start of the three halo column segments (cx-1, cx, cx+1)
+    int offb, offc;             // LDS offsets of segments b and c (segment a starts at 0)
+    int col_a, col_b, col_c;    // wrapped column indices, -1 = outside an open window
     int n_halo;
-    int p0, pn;                // own particles: global slots [p0, p0+pn)
-    int own;                   // LDS index of the first own particle
+    int p0, pn;                 // own particles: global slots [p0, p0+pn)
+    int own;                    // LDS index of the first own particle
 };
+
+__device__ __forceinline__ int tile_col(const Grid &g, int col)
+{
+    if (g.periodic) return col < 0 ? col + g.ncx : (col >= g.ncx ? col - g.ncx : col);
+    return (col < 0 || col >= g.ncx) ? -1 : col;
+}
 
 // uniform per block: every thread computes the same tile from the cell-start table
 __device__ __forceinline__ Tile make_tile(const Grid &g, const int *__restrict__ start, int tile_id, const TileCfg &tc)
@@ -41,34 +49,28 @@ __device__ __forceinline__ Tile make_tile(const Grid &g, const int *__restrict__
     t.r1 = min(t.r0 + tc.ct, g.ncy);
     t.rlo = max(t.r0 - 1, 0);
     t.rhi = min(t.r1, g.ncy - 1);
-    int run = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        int col = t.cx + c - 1;
-        bool valid = true;
-        if (g.periodic) {
-            if (col < 0) col += g.ncx;
-            else if (col >= g.ncx) col -= g.ncx;
-        } else if (col < 0 || col >= g.ncx) {
-            valid = false;
-            col = t.cx;
-        }
-        const int a = start[col * g.ncy + t.rlo], b = start[col * g.ncy + t.rhi + 1];
-        t.g0[c] = a;
-        t.off[c] = run;
-        run += valid ? (b - a) : 0;
-    }
-    t.n_halo = run;
+    t.col_a = tile_col(g, t.cx - 1);
+    t.col_b = t.cx;
+    t.col_c = tile_col(g, t.cx + 1);
+    const int ca = max(t.col_a, 0), cc = max(t.col_c, 0);
+    t.g0a = start[ca * g.ncy + t.rlo];
+    t.g0b = start[t.cx * g.ncy + t.rlo];
+    t.g0c = start[cc * g.ncy + t.rlo];
+    const int na = t.col_a >= 0 ? start[ca * g.ncy + t.rhi + 1] - t.g0a : 0;
+    const int nb = start[t.cx * g.ncy + t.rhi + 1] - t.g0b;
+    const int nc = t.col_c >= 0 ? start[cc * g.ncy + t.rhi + 1] - t.g0c : 0;
+    t.offb = na;
+    t.offc = na + nb;
+    t.n_halo = na + nb + nc;
     t.p0 = start[t.cx * g.ncy + t.r0];
     t.pn = start[t.cx * g.ncy + t.r1] - t.p0;
-    t.own = t.off[1] + (t.p0 - t.g0[1]);
+    t.own = t.offb + (t.p0 - t.g0b);
     return t;
 }
 
 __device__ __forceinline__ int halo_to_global(const Tile &t, int j)
 {
-    const int c = j < t.off[1] ? 0 : (j < t.off[2] ? 1 : 2);
-    return t.g0[c] + (j - t.off[c]);
+    return j < t.offb ? t.g0a + j : (j < t.offc ? t.g0b + (j - t.offb) : t.g0c + (j - t.offc));
 }
 
 // stage one global field into LDS for the whole halo
@@ -84,15 +86,10 @@ __device__ __forceinline__ void stage_cell_starts(const Grid &g, const Tile &t, 
     const int rows = t.rhi - t.rlo + 2;
     for (int e = threadIdx.x; e < 3 * rows; e += kBlock) {
         const int c = e / rows, r = t.rlo + (e - c * rows);
-        int col = t.cx + c - 1;
-        bool valid = true;
-        if (g.periodic) {
-            if (col < 0) col += g.ncx;
-            else if (col >= g.ncx) col -= g.ncx;
-        } else if (col < 0 || col >= g.ncx) {
-            valid = false;
-        }
-        ls[c * (tc.ct + 4) + (r - t.rlo)] = valid ? (start[col * g.ncy + r] - t.g0[c] + t.off[c]) : t.off[c];
+        const int col = c == 0 ? t.col_a : (c == 1 ? t.col_b : t.col_c);
+        const int g0 = c == 0 ? t.g0a : (c == 1 ? t.g0b : t.g0c);
+        const int off = c == 0 ? 0 : (c == 1 ? t.offb : t.offc);
+        ls[c * (tc.ct + 4) + (r - t.rlo)] = col >= 0 ? (start[col * g.ncy + r] - g0 + off) : off;
     }
 }
 

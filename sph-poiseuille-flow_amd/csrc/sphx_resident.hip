@@ -112,6 +112,10 @@ struct sphx_ctx {
     DevBuf<int> kid, counters, n_new;
     SlabPack pack{};
     int64_t slab_steps_enqueued = 0;
+    // each half-step is captured once per parity (and per buffer set) and replayed: 2 graph launches per step
+    // instead of ~14 kernel launches keep the host off the critical path of small slabs
+    hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
+    const void *slab_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
     ~sphx_ctx()
     {
@@ -119,6 +123,7 @@ struct sphx_ctx {
         if (graph) (void)hipGraphDestroy(graph);
         if (pgraph_exec) (void)hipGraphExecDestroy(pgraph_exec);
         if (pgraph) (void)hipGraphDestroy(pgraph);
+        for (auto &h : slab_graph) for (auto &e : h) if (e) (void)hipGraphExecDestroy(e);
         timer.collect();
         timer.drop_graph_events();
         if (h_clock) (void)hipHostFree(h_clock);
@@ -1049,6 +1054,34 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
 
 }  // namespace
 
+namespace {
+
+// run one half of a slab step: replay its captured graph, (re)capturing when the caller's buffers changed
+template <typename Body>
+void slab_half(sphx_ctx *c, int half, int q, const void *const key[3], Body &&body)
+{
+    if (c->profiling) { body(); return; }
+    hipGraphExec_t &exec = c->slab_graph[half][q];
+    const bool same = exec && c->slab_key[half][0] == key[0] && c->slab_key[half][1] == key[1] && c->slab_key[half][2] == key[2];
+    if (!same) {
+        for (int k = 0; k < 2; ++k)
+            if (c->slab_graph[half][k]) { (void)hipGraphExecDestroy(c->slab_graph[half][k]); c->slab_graph[half][k] = nullptr; }
+        for (int k = 0; k < 3; ++k) c->slab_key[half][k] = key[k];
+    }
+    if (!exec) {
+        hipGraph_t g = nullptr;
+        SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        try { body(); } catch (...) { (void)hipStreamEndCapture(c->stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
+        SPHX_HIP(hipStreamEndCapture(c->stream, &g));
+        const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        SPHX_HIP(e);
+    }
+    SPHX_HIP(hipGraphLaunch(exec, c->stream));
+}
+
+}  // namespace
+
 SPHX_EXPORT int sphx_slab_create(sphx_ctx **out, const sphx_params *prm, int n_fluid, int n_total, const double *pos,
                                  const double *vel, const double *drho_dt, const double *mass, const double *wall_vel,
                                  double t0, int64_t step0, int rank, int n_ranks, int halo_cols, void *hip_stream)
@@ -1114,14 +1147,18 @@ SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *se
     require(send_left_dev && send_right_dev && vmax_local_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
     const int q = c->cur;
     const Clock *clk = c->clock.get();
-    launch_physics_any(c, q, 0);
-    launch(c, "k_vmax_reduce", k_vmax_reduce, dim3(1), dim3(kScanBlock), clk, q, c->n_vpart,
-           (const double *)c->vpart.get(), vmax_local_dev);
-    SlabPack p = c->pack;
-    p.send_l = send_left_dev;
-    p.send_r = send_right_dev;
-    launch(c, "k_slab_pack", k_slab_pack, dim3(c->n_blocks_flat), dim3(kBlock), clk, q, c->grid, c->set[q], c->tmp, p);
-    launch(c, "k_slab_seal", k_slab_seal, dim3(1), dim3(1), clk, q, p);
+    auto body = [&]() {
+        launch_physics_any(c, q, 0);
+        launch(c, "k_vmax_reduce", k_vmax_reduce, dim3(1), dim3(kScanBlock), clk, q, c->n_vpart,
+               (const double *)c->vpart.get(), vmax_local_dev);
+        SlabPack p = c->pack;
+        p.send_l = send_left_dev;
+        p.send_r = send_right_dev;
+        launch(c, "k_slab_pack", k_slab_pack, dim3(c->n_blocks_flat), dim3(kBlock), clk, q, c->grid, c->set[q], c->tmp, p);
+        launch(c, "k_slab_seal", k_slab_seal, dim3(1), dim3(1), clk, q, p);
+    };
+    const void *key[3] = {send_left_dev, send_right_dev, vmax_local_dev};
+    slab_half(c, 0, q, key, body);
     SPHX_HIP(hipGetLastError());
     return SPHX_OK;
     SPHX_CATCH
@@ -1136,18 +1173,23 @@ SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const
     const int q = c->cur;
     Clock *clk = c->clock.get();
     const dim3 g1(c->n_blocks_flat), bp(kBlock);
-    launch(c, "k_slab_unpack", k_slab_unpack, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), bp, (const Clock *)clk, q, c->pack,
-           recv_left_dev, recv_right_dev, c->n_new.get(), c->flags.get());
-    // clock: t += dt, new particle count, next dt from the global max |v|.  It arms run[1-q]; the remaining
-    // kernels of this slot still test run[q], and from here on clk->n is the new particle count.
-    launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
-           vmax_global_dev, (const int *)c->flags.get(), (const int *)nullptr, (int *)nullptr, 0, (const int *)c->n_new.get());
-    launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, q, c->grid, 0, (const double *)c->kx.get(), (const double *)c->ky.get(),
-           c->cellid.get(), c->count.get());
-    launch_cell_scan(c, q, c->set[1 - q].start);
-    const double *src[6] = {c->kx.get(), c->ky.get(), c->kvx.get(), c->kvy.get(), c->kdrho.get(), c->kmass.get()};
-    launch_scatter_reorder(c, q, src, c->kid.get(), nullptr);
-    launch(c, "k_slab_reset", k_slab_reset, dim3(1), dim3(1), (const Clock *)clk, q, c->counters.get());
+    auto body = [&]() {
+        launch(c, "k_slab_unpack", k_slab_unpack, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), bp, (const Clock *)clk, q,
+               c->pack, recv_left_dev, recv_right_dev, c->n_new.get(), c->flags.get());
+        // clock: t += dt, new particle count, next dt from the global max |v|.  It arms run[1-q]; the remaining
+        // kernels of this slot still test run[q], and from here on clk->n is the new particle count.
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
+               vmax_global_dev, (const int *)c->flags.get(), (const int *)nullptr, (int *)nullptr, 0,
+               (const int *)c->n_new.get());
+        launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, q, c->grid, 0, (const double *)c->kx.get(),
+               (const double *)c->ky.get(), c->cellid.get(), c->count.get());
+        launch_cell_scan(c, q, c->set[1 - q].start);
+        const double *src[6] = {c->kx.get(), c->ky.get(), c->kvx.get(), c->kvy.get(), c->kdrho.get(), c->kmass.get()};
+        launch_scatter_reorder(c, q, src, c->kid.get(), nullptr);
+        launch(c, "k_slab_reset", k_slab_reset, dim3(1), dim3(1), (const Clock *)clk, q, c->counters.get());
+    };
+    const void *key[3] = {recv_left_dev, recv_right_dev, vmax_global_dev};
+    slab_half(c, 1, q, key, body);
     SPHX_HIP(hipGetLastError());
     c->cur ^= 1;
     c->slab_steps_enqueued += 1;

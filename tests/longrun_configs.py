@@ -1,0 +1,31 @@
+"""Manual validation runs of the larger BASELINE.json configurations (not collected by pytest):
+    python tests/longrun_configs.py C3 20     # dp = 0.01, DL = 6, 20 s
+Writes gpurun_out/longrun_<name>.json (steps, wall time, L2 against the analytic profile, wall shear)."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("sph-poiseuille-flow_amd")
+CASES = {"C1": dict(dp=0.04, DL=3.0), "C2": dict(dp=0.025, DL=3.0), "C3": dict(dp=0.01, DL=6.0), "C4": dict(dp=0.005, DL=12.0)}
+
+
+def main():
+    name, t_end = sys.argv[1], float(sys.argv[2])
+    prm = pkg.config.params_from_values(end_time=t_end, output_interval=max(t_end / 4, 1e-3), **CASES[name])
+    res = pkg.driver.run(prm, log=lambda s: print(s, flush=True))
+    out = dict(name=name, n_total=res.n_total, steps=res.steps, t=res.t, wall_seconds=res.wall_seconds, L2=res.L2_error,
+               particle_steps_per_s=res.particle_steps_per_s, tau_bottom=res.tau_bottom, tau_top=res.tau_top,
+               tau_target=res.tau_target, u_mean=np.nan_to_num(res.u_mean).tolist(), u_exact=res.u_exact.tolist())
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"longrun_{name}_{t_end:g}s.json"), "w") as f:
+        json.dump(out, f)
+    print({k: out[k] for k in ("name", "n_total", "steps", "wall_seconds", "L2", "particle_steps_per_s", "tau_bottom", "tau_top")})
+
+
+if __name__ == "__main__":
+    main()
