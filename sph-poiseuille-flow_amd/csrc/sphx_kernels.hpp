@@ -188,19 +188,54 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     const bool active = i < n;
     double s_in = 0.0, s_ct = 0.0;
     int cnt = 0;
+    // The LPP lanes of a particle test LPP consecutive candidates at a time; the accepted ones are packed
+    // (ballot + popcount) into ONE list per particle whose entry m belongs to lane m % LPP, row m / LPP.  Every
+    // lane then owns ceil-or-floor(cnt / LPP) neighbours in the later passes (balanced trip counts) and the lanes
+    // of a group walk adjacent particles, so a gather touches a few cache lines instead of ~27.
     if (active) {
         const double xi = s.x[i], yi = s.y[i];
         int cx, cy;
         cell_of(g, xi, yi, cx, cy);
-        sweep<LPP>(g, s.start, cx, cy, sub, [&](int k) {
-            const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
-            const double r2 = dx * dx + dy * dy;
-            if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                s_in += spline_W(ph.kc, r2 * rsqrt(r2));
-                if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = k;
-                ++cnt;
+        const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
+        const int row_base = tid - sub;  // list column of lane 0 of this group
+        const int cylo = max(cy - 1, 0), cyhi = min(cy + 1, g.ncy - 1);
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox) {
+            int col = cx + ox;
+            if (g.periodic) {
+                if (col < 0) col += g.ncx;
+                else if (col >= g.ncx) col -= g.ncx;
+            } else if (col < 0 || col >= g.ncx) {
+                continue;
             }
-        });
+            const int lo = s.start[col * g.ncy + cylo], hi = s.start[col * g.ncy + cyhi + 1];
+            for (int kb = lo; kb < hi; kb += LPP) {  // uniform over the group
+                const int k = kb + sub;
+                bool acc = false;
+                if (k < hi) {
+                    const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+                    const double r2 = dx * dx + dy * dy;
+                    if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                        acc = true;
+                        s_in += spline_W(ph.kc, r2 * rsqrt(r2));
+                    }
+                }
+                if (LPP == 1) {
+                    if (acc) {
+                        if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = k;
+                        ++cnt;
+                    }
+                } else {
+                    const unsigned long long bal = __ballot(acc);
+                    const unsigned long long grp = (bal >> gbase) & ((1ull << LPP) - 1ull);
+                    if (acc) {
+                        const int m = cnt + __popcll(grp & ((1ull << sub) - 1ull));
+                        if (m / LPP < t.nl_cap) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = k;
+                    }
+                    cnt += __popcll(grp);
+                }
+            }
+        }
         if (w.row_any[cy]) {
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
                 const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
@@ -208,9 +243,11 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * w.Vol[k];
             });
         }
-        if (cnt > t.nl_cap) { atomicOr(t.flags, 1); cnt = t.nl_cap; }
+        if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
     }
-    if (tid < t.nl_stride) t.nl_cnt[tid] = cnt;
+    // cnt is the particle's neighbour count (identical in all lanes of the group); lane `sub` owns entries
+    // sub, sub+LPP, ...
+    if (tid < t.nl_stride) t.nl_cnt[tid] = cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0;
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {
