@@ -446,6 +446,64 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     }
 }
 
+// block-wide exclusive scan of one int per thread (NT threads); returns the block total
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan_t(int v, int &total, int *s_wave /*[NT/64+1]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const int ws = lane < NT / 64 ? s_wave[lane] : 0;
+        int winc = ws;
+#pragma unroll
+        for (int off = 1; off < NT / 64; off <<= 1) {
+            const int o = __shfl_up(winc, off);
+            if (lane >= off) winc += o;
+        }
+        if (lane < NT / 64) s_wave[lane] = winc - ws;  // exclusive wave offsets
+        if (lane == NT / 64 - 1) s_wave[NT / 64] = winc;
+    }
+    __syncthreads();
+    const int res = s_wave[wave] + inc - v;
+    total = s_wave[NT / 64];
+    __syncthreads();
+    return res;
+}
+
+// advance the device clock by the step that has just been computed (one thread)
+__device__ __forceinline__ void clock_step(Clock *clk, int q, const Phys &ph, double vmax, const int *flags,
+                                           const int *n_new)
+{
+    Clock c = *clk;
+    c.vmax = vmax;
+    c.t += c.dt;  // SPH_Poiseuille.m:267
+    c.dt_last = c.dt;
+    c.step += 1;
+    if (c.steps_left > 0) c.steps_left -= 1;
+    if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
+    if (*flags) c.status = SPHX_ERR_GRID;  // neighbour-list / slab-buffer overflow
+    if (n_new) c.n = *n_new;
+    c.dt = next_dt(c, ph);
+    c.run[1 - q] = loop_continues(c) ? 1 : 0;
+    *clk = c;
+}
+
+// Small grids: the LAST workgroup of k_continuity to finish also advances the clock and scans the cell
+// histogram, which saves the k_clock_scan launch (~4.5 us of a ~46 us step at 5 k particles).
+struct FuseClock {
+    int enable;
+    unsigned int *ticket;  // [1] arrival counter, zero between launches
+    int *start_next;       // [ncells+1]
+    int ncells, n_vpart;
+};
+
 // ---------------------------------------------------------------------------------------------
 // pass E: continuity rate with the kicked velocities (integration_2nd, sph_physics_mex.c:1076-1116),
 // final half-step of rho and EOS (:1440-1450), per-block max |v|^2 over owned particles for the next
@@ -453,10 +511,13 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
 // (neighbour rebuild, the K0 insert of mex/sph_neighbor_search_mex.c:269-296).
 // ---------------------------------------------------------------------------------------------
 template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, Grid g, Phys ph,
-                                                       FluidSet s, FluidTmp t, Walls w, int do_hist)
+__global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
+                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, FuseClock fc)
 {
-    if (!clk->run[q]) return;
+    if (!clk->run[q]) {
+        if (fc.enable && blockIdx.x == 0 && threadIdx.x == 0) clk->run[1 - q] = 0;
+        return;
+    }
     const int n = clk->n;
     const int blk = xcd_block(blockIdx.x, gridDim.x);
     const int tid = blk * kBlock + threadIdx.x;
@@ -526,6 +587,46 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
         for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_max[k]);
         t.vpart[blk] = m;
     }
+    if (!fc.enable) return;
+    // ---- last workgroup: clock + cell scan (arrival counter; release/acquire at agent scope as in
+    //      cdna_hip_programming.md Guideline 16: stores -> release fence -> vmcnt(0) -> counter add)
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = (atomicAdd(fc.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    double m = 0.0;
+    for (int k = threadIdx.x; k < fc.n_vpart; k += kBlock) m = fmax(m, t.vpart[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    __shared__ double s_m2[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_m2[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_m2[k]);
+        clock_step(clk, q, ph, sqrt(m), t.flags, nullptr);
+        *fc.ticket = 0u;
+    }
+    // exclusive scan of the histogram; the counts were produced by atomics on all XCDs, read them the same way
+    __shared__ int s_wave[kBlock / 64 + 1];
+    int carry = 0;
+    for (int base = 0; base < fc.ncells; base += kBlock) {
+        const int idx = base + (int)threadIdx.x;
+        const int v = idx < fc.ncells ? atomicAdd(&t.count[idx], 0) : 0;
+        int total;
+        const int ex = block_exclusive_scan_t<kBlock>(v, total, s_wave);
+        if (idx < fc.ncells) fc.start_next[idx] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) fc.start_next[fc.ncells] = carry;
 }
 
 // standalone cell histogram (context creation, wall grid, slab steps): same binning as pass E
@@ -634,18 +735,7 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
-        Clock c = *clk;
-        c.vmax = vmax_global ? *vmax_global : sqrt(m);  // max of sqrt == sqrt of max (monotone)
-        c.t += c.dt;                                    // SPH_Poiseuille.m:267
-        c.dt_last = c.dt;
-        c.step += 1;
-        if (c.steps_left > 0) c.steps_left -= 1;
-        if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
-        if (*flags) c.status = SPHX_ERR_GRID;  // neighbour-list / slab-buffer overflow
-        if (n_new) c.n = *n_new;
-        c.dt = next_dt(c, ph);
-        c.run[1 - q] = loop_continues(c) ? 1 : 0;
-        *clk = c;
+        clock_step(clk, q, ph, vmax_global ? *vmax_global : sqrt(m), flags, n_new);  // max of sqrt == sqrt of max
     }
     if (count) scan_counts(count, start_next, n_scan);
 }

@@ -77,6 +77,7 @@ struct sphx_ctx {
     DevBuf<double> fx_[2], fy_[2], fvx_[2], fvy_[2], fdrho_[2], fmass_[2];
     DevBuf<int> fid_[2], fstart_[2];
     DevBuf<double> xn, yn, vxn, vyn, drhon, rho, Vol, rhoh, ph, b11, b12, b21, b22, fpx, fpy, ffx, ffy, rho_out, p_out, vpart;
+    DevBuf<unsigned int> ticket;
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, flags, tile;
     DevBuf<double> wx, wy, wVol, wvx, wvy;
     DevBuf<int> wid, wstart, wrow_any;
@@ -184,10 +185,12 @@ ReorderArgs reorder_args(const double *const src[6], const int *id_src, const Fl
 
 // only: 0 = all four neighbour passes, 1..4 = just density / kgc / forces / continuity (kernel timing)
 template <int LPP>
-void launch_physics(sphx_ctx *c, int q, int do_hist, int only = 0)
+void launch_physics(sphx_ctx *c, int q, int do_hist, int only = 0, bool fuse_clock = false)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
+    FuseClock fc{};
+    if (fuse_clock) fc = FuseClock{1, c->ticket.get(), c->set[1 - q].start, c->grid.ncells, c->n_vpart};
     const FluidSet &s = c->set[q];
     if (c->tiled) {
         const TileCfg tc = c->tcfg;
@@ -212,18 +215,18 @@ void launch_physics(sphx_ctx *c, int q, int do_hist, int only = 0)
     if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
     if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
     if (!only || only == 4)
-        launch(c, "k_continuity", k_continuity<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls, do_hist);
+        launch(c, "k_continuity", k_continuity<LPP>, gp, bp, c->clock.get(), q, c->grid, c->phys, s, c->tmp, c->walls, do_hist, fc);
 }
 
-void launch_physics_any(sphx_ctx *c, int q, int do_hist, int only = 0)
+void launch_physics_any(sphx_ctx *c, int q, int do_hist, int only = 0, bool fuse_clock = false)
 {
     switch (c->lpp) {
-        case 1: launch_physics<1>(c, q, do_hist, only); break;
-        case 2: launch_physics<2>(c, q, do_hist, only); break;
-        case 4: launch_physics<4>(c, q, do_hist, only); break;
-        case 8: launch_physics<8>(c, q, do_hist, only); break;
-        case 16: launch_physics<16>(c, q, do_hist, only); break;
-        case 32: launch_physics<32>(c, q, do_hist, only); break;
+        case 1: launch_physics<1>(c, q, do_hist, only, fuse_clock); break;
+        case 2: launch_physics<2>(c, q, do_hist, only, fuse_clock); break;
+        case 4: launch_physics<4>(c, q, do_hist, only, fuse_clock); break;
+        case 8: launch_physics<8>(c, q, do_hist, only, fuse_clock); break;
+        case 16: launch_physics<16>(c, q, do_hist, only, fuse_clock); break;
+        case 32: launch_physics<32>(c, q, do_hist, only, fuse_clock); break;
         default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
     }
 }
@@ -259,11 +262,16 @@ void launch_scatter_reorder(sphx_ctx *c, int q, const double *const src[6], cons
 // one single-GPU step slot of parity q
 void launch_step(sphx_ctx *c, int q)
 {
-    launch_physics_any(c, q, 1);
+    const bool fuse = !c->big_scan && !c->tiled;  // small grids: the last k_continuity workgroup runs the clock + scan
+    launch_physics_any(c, q, 1, 0, fuse);
     Clock *clk = c->clock.get();
     const FluidSet &s = c->set[q];
     const FluidSet &d = c->set[1 - q];
     const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
+    if (fuse) {
+        launch_scatter_reorder(c, q, src, s.id, c->tmp.src_of);
+        return;
+    }
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(),
@@ -367,9 +375,10 @@ void fill_status(sphx_ctx *c, sphx_status *st)
 
 int pick_lpp(int nf)
 {
-    // enough lanes to put ~2 waves on each of the 1024 SIMDs, never more than 32 lanes per particle
-    const long target = 256L * 4 * 2 * 64;
-    int lpp = 1;
+    // enough lanes to put ~4 waves on each of the 1024 SIMDs; 4..32 lanes per particle (measured: with the
+    // balanced neighbour list 4 lanes beat 1-2 even at 6 M particles, 32 beat 16 at 5 k)
+    const long target = 256L * 4 * 4 * 64;
+    int lpp = 4;
     while (lpp < 32 && (long)nf * lpp * 2 <= target) lpp *= 2;
     return lpp;
 }
@@ -447,6 +456,8 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->nl_cnt.zero(c->stream);
     c->flags.alloc(1);
     c->flags.zero(c->stream);
+    c->ticket.alloc(1);
+    c->ticket.zero(c->stream);
     c->big_scan = g.ncells > kBigScanCells;
     c->n_tiles = (int)div_up((size_t)g.ncells, kScanBlock);
     c->tile.alloc(2 * ((size_t)c->n_tiles + 1));
