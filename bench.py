@@ -91,7 +91,8 @@ def pmc_traffic(name, kernel):
         return None
 
 
-def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=0, tile=0, lattice=False):
+def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=0, tile=0, lattice=False,
+             rebuild_every=0, skin_h=0.0):
     """Time `steps` resident steps of one workload; returns (result dict, prm, parts, pos, vel)."""
     import torch
     prm = cfg.params_from_values(end_time=1e9, **kw)
@@ -103,7 +104,8 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
         pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
         start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
     ctx = capi.Context(prm, nf, nt, pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9,
-                       lanes_per_particle=lpp, steps_per_graph=spg, tile_cells=tile)
+                       lanes_per_particle=lpp, steps_per_graph=spg, tile_cells=tile, rebuild_every=rebuild_every,
+                       skin_h=skin_h)
     info, tuning = ctx.info(), ctx.tuning()
     if warmup > 0:
         ctx.enqueue_steps(warmup)  # untimed: includes graph capture/instantiation
@@ -135,6 +137,7 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
                         frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(name, dom), launch_ms=ms, launch_ms_eager=ms_eager,
                         algorithmic_bytes=alg,
                         step_achieved=(STEP_BYTES_FLUID * nf + STEP_BYTES_WALL * nw) * steps / seconds / 1e9)
+    tuning.update(ctx.grid_policy())
     ctx.close()
     res = dict(value=nt * steps / seconds, ms_per_step=1e3 * seconds / steps, seconds=seconds, roofline=roof,
                kernels_ms={k: round(v["avg_ms"], 6) for k, v in kernels.items()},
@@ -154,6 +157,8 @@ def main():
     ap.add_argument("--lpp", type=int, default=0, help="lanes per particle (0 = auto)")
     ap.add_argument("--spg", type=int, default=0, help="steps per hipGraph replay (0 = auto)")
     ap.add_argument("--tile", type=int, default=0, help="cells per LDS tile (0 = auto, -1 = list-walking kernels only)")
+    ap.add_argument("--rebuild-every", type=int, default=0, help="re-bin particles every K-th step (0 = auto)")
+    ap.add_argument("--skin", type=float, default=0.0, help="cell skin in units of h (0 = sized from K)")
     ap.add_argument("--profile-steps", type=int, default=200, help="eager steps timed per kernel with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the C4/C5 side measurements of the default run")
@@ -184,7 +189,7 @@ def main():
 
     name, kw = parse_workload(args.workload or "C2")
     r, prm, parts, pos, vel = run_case(capi, cfg, geo, name, kw, args.steps, args.warmup, args.profile_steps, args.lpp,
-                                       args.spg, args.tile, args.lattice)
+                                       args.spg, args.tile, args.lattice, args.rebuild_every, args.skin)
     value = r["value"]
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
@@ -193,6 +198,8 @@ def main():
         "config": {"workload": r["workload"], "cells": r["cells"],
                    "lanes_per_particle": r["tuning"]["lanes_per_particle"],
                    "steps_per_graph": r["tuning"]["steps_per_graph"],
+                   "rebuild_every": r["tuning"]["rebuild_every"], "skin": r["tuning"]["skin"],
+                   "forced_rebuilds": r["tuning"]["forced_rebuilds"],
                    "parallelism": "1 GPU, device-resident loop, hipGraph replay"},
         "roofline": r["roofline"], "kernels_ms": r["kernels_ms"], "sim": r["sim"],
     }

@@ -146,6 +146,12 @@ typedef struct sphx_params {
     int32_t steps_per_graph;    /* 0 = auto; steps captured per hipGraph replay (even)               */
     int32_t reserved;           /* tile_cells: >0 = experimental LDS-tiled neighbour passes with that many
                                    cells per tile; <=0 = list-walking passes (default)                 */
+    int32_t rebuild_every;      /* 0 = auto; K >= 1: particles are re-binned into cells every K-th step; in
+                                   between, sweeps are centred on the cell a particle was binned into and
+                                   the cells carry a skin (results do not depend on K beyond summation
+                                   order: the device stops and re-bins before any neighbour can be missed) */
+    int32_t reserved2;
+    double skin_h;              /* cell skin in units of h for K > 1; <= 0 = sized from K                  */
 } sphx_params;
 
 typedef struct sphx_status {
@@ -201,6 +207,12 @@ int sphx_ctx_profile_read(sphx_ctx *ctx, int capacity, const char **names, doubl
 int sphx_ctx_time_kernel(sphx_ctx *ctx, const char *name, int reps, double *avg_ms);
 
 /* The launch shape the context chose (lanes cooperating per particle, steps per hipGraph replay). */
+/* Cell-grid policy in force: rebuild interval K (shrinks by one whenever the device had to stop for an
+ * unscheduled re-bin), skin in length units, the number of such unscheduled re-bins so far, and the largest
+ * distance of any particle from where it was binned (as of the last advance / sync; must stay <= skin/2). */
+int sphx_ctx_grid_policy(sphx_ctx *ctx, int *rebuild_every, double *skin, int64_t *forced_rebuilds,
+                         double *drift);
+
 int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph);
 
 /* Global particle counts and the cell grid the context built. */

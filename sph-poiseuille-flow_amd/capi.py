@@ -30,7 +30,8 @@ class SphxParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("DL", "DH", "dp", "h", "rho0", "mu", "c_f", "p0", "inv_sigma0",
                                            "gravity_g", "transport_coeff", "t_end")] + \
                [("sort_interval", C.c_int32), ("lanes_per_particle", C.c_int32),
-                ("steps_per_graph", C.c_int32), ("reserved", C.c_int32)]
+                ("steps_per_graph", C.c_int32), ("reserved", C.c_int32), ("rebuild_every", C.c_int32),
+                ("reserved2", C.c_int32), ("skin_h", C.c_double)]
 
 
 class SphxStatus(C.Structure):
@@ -48,7 +49,7 @@ EXPORTS = [
     "sphx_integration_verlet", "sphx_advance_shell_step", "sphx_wall_shear_monitor",
     "sphx_ctx_create", "sphx_ctx_destroy", "sphx_ctx_advance", "sphx_ctx_enqueue_steps", "sphx_ctx_sync",
     "sphx_ctx_download", "sphx_ctx_monitor", "sphx_ctx_neighbor_list", "sphx_ctx_profile_enable",
-    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_time_kernel",
+    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_grid_policy", "sphx_ctx_time_kernel",
     "sphx_slab_create", "sphx_slab_layout", "sphx_slab_local_vmax", "sphx_slab_prepare", "sphx_slab_compute",
     "sphx_slab_finish", "sphx_slab_sync", "sphx_slab_snapshot",
 ]
@@ -96,23 +97,26 @@ def set_device(dev: int) -> None:
     check(lib().sphx_set_device(C.c_int(dev)))
 
 
-def make_params(prm, t_end=None, transport_coeff=None, lanes_per_particle=0, steps_per_graph=0, tile_cells=0) -> SphxParams:
+def make_params(prm, t_end=None, transport_coeff=None, lanes_per_particle=0, steps_per_graph=0, tile_cells=0,
+                rebuild_every=0, skin_h=0.0) -> SphxParams:
     return SphxParams(DL=prm.DL, DH=prm.DH, dp=prm.dp, h=prm.h, rho0=prm.rho0, mu=prm.mu, c_f=prm.c_f,
                       p0=prm.p0, inv_sigma0=prm.inv_sigma0, gravity_g=prm.gravity_g,
                       transport_coeff=prm.transport_coeff if transport_coeff is None else transport_coeff,
                       t_end=prm.t_end if t_end is None else t_end, sort_interval=int(prm.sort_interval),
                       lanes_per_particle=int(lanes_per_particle), steps_per_graph=int(steps_per_graph),
-                      reserved=int(tile_cells))
+                      reserved=int(tile_cells), rebuild_every=int(rebuild_every), reserved2=0, skin_h=float(skin_h))
 
 
 class Context:
     """Device-resident simulation state (sphx_ctx)."""
 
     def __init__(self, prm, n_fluid, n_total, pos, vel, drho_dt, mass, wall_vel, t0=0.0, step0=0,
-                 t_end=None, transport_coeff=None, lanes_per_particle=0, steps_per_graph=0, tile_cells=0):
+                 t_end=None, transport_coeff=None, lanes_per_particle=0, steps_per_graph=0, tile_cells=0,
+                 rebuild_every=0, skin_h=0.0):
         self._h = C.c_void_p()
         self.n_fluid, self.n_total = int(n_fluid), int(n_total)
-        self.params = make_params(prm, t_end, transport_coeff, lanes_per_particle, steps_per_graph, tile_cells)
+        self.params = make_params(prm, t_end, transport_coeff, lanes_per_particle, steps_per_graph, tile_cells,
+                                  rebuild_every, skin_h)
         pos, vel, wall_vel = f64(pos), f64(vel), f64(wall_vel)
         drho_dt, mass = f64(drho_dt), f64(mass)
         assert pos.shape == (n_total, 2) and vel.shape == (n_total, 2) and wall_vel.shape == (n_total, 2)
@@ -172,6 +176,11 @@ class Context:
         a, b, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().sphx_ctx_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(n_fluid=a.value, n_wall=b.value, n_cell_x=c.value, n_cell_y=d.value)
+
+    def grid_policy(self):
+        a, b, c, d = C.c_int(0), C.c_double(0.0), C.c_int64(0), C.c_double(0.0)
+        check(lib().sphx_ctx_grid_policy(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(rebuild_every=a.value, skin=b.value, forced_rebuilds=c.value, drift=d.value)
 
     def tuning(self):
         a, b = C.c_int(0), C.c_int(0)

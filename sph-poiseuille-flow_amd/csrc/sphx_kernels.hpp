@@ -52,12 +52,17 @@ struct Clock {
     int run[2];                  // run[q]: the step slot of parity q executes
     int status;
     int n;                       // particles currently held (fluid, incl. slab halo copies)
+    double drift;                // largest distance of any particle from where it was when the grid was built
+    int need_rebuild;            // 1: drift exceeded half the cell skin -> the loop stopped, host must re-bin
+    int pad;
 };
 
 struct FluidSet {  // persistent per-particle state, sorted by cell
     double *x, *y, *vx, *vy, *drho, *mass;
     int *id;
     int *start;  // [ncells+1] cell ranges of this ordering
+    int *cell;   // [n] the cell each slot was BINNED into (positions may since have drifted by < skin/2)
+    double *xb, *yb;  // [n] position at binning time (nullptr: grid rebuilt every step, drift not tracked)
 };
 
 struct FluidTmp {
@@ -66,6 +71,7 @@ struct FluidTmp {
     double *fpx, *fpy, *fx, *fy, *rho_out, *p_out;         // outputs of the step
     int *cellid, *count, *perm, *src_of;
     double *vpart;   // per-block max |v|^2 of pass E (owned particles only)
+    double *dpart;   // per-block max drift^2 from the binning positions after this step (pass CD)
     int *nl_idx;     // neighbour list, entry m of lane l at nl_idx[m*nl_stride + l]
     int *nl_cnt;     // [nl_stride] entries per lane
     int *flags;      // [1] sticky device status bits (list overflow ...)
@@ -87,6 +93,15 @@ __device__ __forceinline__ void cell_of(const Grid &g, double x, double y, int &
     cx = min(max(cx, 0), g.ncx - 1);
     cy = (int)floor((y - g.y0) * g.inv_csy);
     cy = min(max(cy, 0), g.ncy - 1);
+}
+
+// the cell a slot is stored in (set when the grid was built); sweeps are centred on it, not on the cell of the
+// current position, because between two grid builds particles drift by up to skin/2
+__device__ __forceinline__ void binned_cell(const Grid &g, const FluidSet &s, int i, int &cx, int &cy)
+{
+    const int c = s.cell[i];
+    cx = c / g.ncy;
+    cy = c - cx * g.ncy;
 }
 
 __device__ __forceinline__ double wrap_x(double x, double DL) { return x - floor(x / DL) * DL; }
@@ -151,7 +166,7 @@ __device__ __forceinline__ double next_dt(const Clock &c, const Phys &ph)
 
 __device__ __forceinline__ bool loop_continues(const Clock &c)
 {  // while state.t < target_time - 1e-12 (SPH_Poiseuille.m:250) and step budget left
-    return (c.t < c.t_target - 1e-12) && (c.steps_left != 0) && (c.status == 0);
+    return (c.t < c.t_target - 1e-12) && (c.steps_left != 0) && (c.status == 0) && (c.need_rebuild == 0);
 }
 
 // one thread: arm the clock for an advance call.  vmax_in (optional) overrides the stored vmax (slab:
@@ -195,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     if (active) {
         const double xi = s.x[i], yi = s.y[i];
         int cx, cy;
-        cell_of(g, xi, yi, cx, cy);
+        binned_cell(g, s, i, cx, cy);
         const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
         const int row_base = tid - sub;  // list column of lane 0 of this group
         const int cylo = max(cy - 1, 0), cyhi = min(cy + 1, g.ncy - 1);
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
             term(min_image(g, xi - s.x[k]), yi - s.y[k], t.Vol[k]);
         }
         int cx, cy;
-        cell_of(g, xi, yi, cx, cy);
+        binned_cell(g, s, i, cx, cy);
         if (w.row_any[cy]) {
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
                 const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     const int i = tid / LPP, sub = tid % LPP;
     const bool active = i < n;
     const double h = ph.kc.h;
-    double ax = 0.0, ay = 0.0, ix = 0.0, iy = 0.0, px = 0.0, py = 0.0;
+    double ax = 0.0, ay = 0.0, ix = 0.0, iy = 0.0, px = 0.0, py = 0.0, d2 = 0.0;
     double xi = 0.0, yi = 0.0, vxi = 0.0, vyi = 0.0, Voli = 0.0, mi = 1.0, p_i = 0.0, rhoh_i = 0.0;
     double b11i = 1.0, b12i = 0.0, b21i = 0.0, b22i = 1.0;
     int cx = 0, cy = 0;
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
             px -= (p_face * tx) * dWVj;
             py -= (p_face * ty) * dWVj;
         }
-        cell_of(g, xi, yi, cx, cy);
+        binned_cell(g, s, i, cx, cy);
         near_wall = w.row_any[cy] != 0;
         if (near_wall) {
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
@@ -435,6 +450,11 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         yo += 0.5 * dt * vyi;
         xo += 0.5 * dt * vxn;
         yo += 0.5 * dt * vyn;
+        if (s.xb) {
+            const double ddx = min_image(g, xo - s.xb[i]), ddy = yo - s.yb[i];
+            d2 = ddx * ddx + ddy * ddy;
+            if (d2 != d2) d2 = INFINITY;
+        }
         t.xn[i] = g.periodic ? wrap_x(xo, ph.DL) : xo;  // a slab wraps when particles change owner
         t.yn[i] = yo;
         t.vxn[i] = vxn;
@@ -443,6 +463,17 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         t.fpy[i] = fpy;
         t.fx[i] = fx;
         t.fy[i] = fy;
+    }
+    // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off));
+    __shared__ double s_d2[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_d2[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_d2[0];
+        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_d2[k]);
+        t.dpart[blk] = m;
     }
 }
 
@@ -478,10 +509,18 @@ __device__ __forceinline__ int block_exclusive_scan_t(int v, int &total, int *s_
 }
 
 // advance the device clock by the step that has just been computed (one thread)
+// drift: largest distance from the binning positions (< 0: not tracked); rebuilt: this step ends with a fresh grid.
 __device__ __forceinline__ void clock_step(Clock *clk, int q, const Phys &ph, double vmax, const int *flags,
-                                           const int *n_new)
+                                           const int *n_new, double drift = -1.0, int rebuilt = 1,
+                                           double half_skin = 0.0)
 {
     Clock c = *clk;
+    if (drift >= 0.0) {
+        c.drift = rebuilt ? 0.0 : drift;
+        // every step sweeps the cells the particles were BINNED into; that finds all neighbours only while no
+        // particle has drifted more than half the skin -> stop the loop, the host re-bins and resumes
+        if (!(c.drift <= half_skin)) c.need_rebuild = 1;
+    }
     c.vmax = vmax;
     c.t += c.dt;  // SPH_Poiseuille.m:267
     c.dt_last = c.dt;
@@ -495,15 +534,6 @@ __device__ __forceinline__ void clock_step(Clock *clk, int q, const Phys &ph, do
     *clk = c;
 }
 
-// Small grids: the LAST workgroup of k_continuity to finish also advances the clock and scans the cell
-// histogram, which saves the k_clock_scan launch (~4.5 us of a ~46 us step at 5 k particles).
-struct FuseClock {
-    int enable;
-    unsigned int *ticket;  // [1] arrival counter, zero between launches
-    int *start_next;       // [ncells+1]
-    int ncells, n_vpart;
-};
-
 // ---------------------------------------------------------------------------------------------
 // pass E: continuity rate with the kicked velocities (integration_2nd, sph_physics_mex.c:1076-1116),
 // final half-step of rho and EOS (:1440-1450), per-block max |v|^2 over owned particles for the next
@@ -511,13 +541,10 @@ struct FuseClock {
 // (neighbour rebuild, the K0 insert of mex/sph_neighbor_search_mex.c:269-296).
 // ---------------------------------------------------------------------------------------------
 template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
-                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, FuseClock fc)
+__global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, Grid g, Phys ph,
+                                                       FluidSet s, FluidTmp t, Walls w, int do_hist)
 {
-    if (!clk->run[q]) {
-        if (fc.enable && blockIdx.x == 0 && threadIdx.x == 0) clk->run[1 - q] = 0;
-        return;
-    }
+    if (!clk->run[q]) return;
     const int n = clk->n;
     const int blk = xcd_block(blockIdx.x, gridDim.x);
     const int tid = blk * kBlock + threadIdx.x;
@@ -540,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
             rate += u_jump * spline_dW(ph.kc, r) * t.Vol[k];
         }
         int cx, cy;
-        cell_of(g, xi, yi, cx, cy);
+        binned_cell(g, s, i, cx, cy);
         if (w.row_any[cy]) {
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
                 const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
@@ -587,46 +614,6 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
         for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_max[k]);
         t.vpart[blk] = m;
     }
-    if (!fc.enable) return;
-    // ---- last workgroup: clock + cell scan (arrival counter; release/acquire at agent scope as in
-    //      cdna_hip_programming.md Guideline 16: stores -> release fence -> vmcnt(0) -> counter add)
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = (atomicAdd(fc.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    double m = 0.0;
-    for (int k = threadIdx.x; k < fc.n_vpart; k += kBlock) m = fmax(m, t.vpart[k]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    __shared__ double s_m2[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_m2[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_m2[k]);
-        clock_step(clk, q, ph, sqrt(m), t.flags, nullptr);
-        *fc.ticket = 0u;
-    }
-    // exclusive scan of the histogram; the counts were produced by atomics on all XCDs, read them the same way
-    __shared__ int s_wave[kBlock / 64 + 1];
-    int carry = 0;
-    for (int base = 0; base < fc.ncells; base += kBlock) {
-        const int idx = base + (int)threadIdx.x;
-        const int v = idx < fc.ncells ? atomicAdd(&t.count[idx], 0) : 0;
-        int total;
-        const int ex = block_exclusive_scan_t<kBlock>(v, total, s_wave);
-        if (idx < fc.ncells) fc.start_next[idx] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) fc.start_next[fc.ncells] = carry;
 }
 
 // standalone cell histogram (context creation, wall grid, slab steps): same binning as pass E
@@ -716,26 +703,32 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(const Clock *clk, int q
 // Step kernel 5: finish the clock of this step (vmax -> next dt, t += dt, stop test) and scan the
 // cell histogram (small grids) or the tile sums (big grids).  Single block.
 //   vmax_global: slab mode -- the all-reduced max |v| replaces the local reduction.
+//   dpart / rebuilt / half_skin: displacement bookkeeping of grids that are rebuilt only every few steps.
 __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Phys ph, int n_vpart,
                                                            const double *vpart, const double *vmax_global,
                                                            const int *flags, const int *count,
-                                                           int *start_next, int n_scan, const int *n_new)
+                                                           int *start_next, int n_scan, const int *n_new,
+                                                           const double *dpart, int rebuilt, double half_skin)
 {
     if (!clk->run[q]) {
         if (threadIdx.x == 0) clk->run[1 - q] = 0;
         return;
     }
-    double m = 0.0;
+    double m = 0.0, d = 0.0;
     if (!vmax_global)
         for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
+    if (dpart)
+        for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) d = fmax(d, dpart[k]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    __shared__ double s_m[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); d = fmax(d, __shfl_xor(d, off)); }
+    __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
-        clock_step(clk, q, ph, vmax_global ? *vmax_global : sqrt(m), flags, n_new);  // max of sqrt == sqrt of max
+        for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
+        // max of sqrt == sqrt of max (monotone, correctly rounded)
+        clock_step(clk, q, ph, vmax_global ? *vmax_global : sqrt(m), flags, n_new, dpart ? sqrt(d) : -1.0, rebuilt,
+                   half_skin);
     }
     if (count) scan_counts(count, start_next, n_scan);
 }
@@ -785,6 +778,7 @@ struct ReorderArgs {
     const int *id_src;
     int *id_dst;
     int *src_of;
+    int *cell_dst;  // binned cell of every destination slot (nullptr: not needed, walls)
 };
 
 // Step kernel 7: canonical rank inside the cell (ascending particle id -> an order that does not
@@ -812,6 +806,13 @@ __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int
         if (f < a.nd) a.dst[f][dst] = a.src[f][i];
     a.id_dst[dst] = my_id;
     if (a.src_of) a.src_of[dst] = i;
+    if (a.cell_dst) a.cell_dst[dst] = c;
+}
+
+__global__ void k_rebinned(Clock *clk)
+{
+    clk->drift = 0.0;
+    clk->need_rebuild = 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_iota(int n, int *a, int base)
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(kScanBlock) void k_vmax_init(Clock *clk, Grid g, co
 // wall shear (sph_physics_mex.c:1713-1742): new neighbour structure, new pos/vel, Vol/B of the step
 // that just finished (reached through src_of).  Per-block partial sums, reduced by k_tau_final.
 __global__ __launch_bounds__(kBlock) void k_wall_shear(const Clock *clk, Grid g, Phys ph, FluidSet s, FluidTmp t,
-                                                       Walls w, double *part /*[2*grid]*/)
+                                                       Walls w, int use_src, double *part /*[2*grid]*/)
 {
     const int n = clk->n;
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -884,9 +885,9 @@ __global__ __launch_bounds__(kBlock) void k_wall_shear(const Clock *clk, Grid g,
     if (i < n) {
         const double xi = s.x[i], yi = s.y[i];
         int cx, cy;
-        cell_of(g, xi, yi, cx, cy);
+        binned_cell(g, s, i, cx, cy);
         if (w.row_any[cy] && xi >= g.own_lo && xi < g.own_hi) {
-            const int o = t.src_of[i];
+            const int o = use_src ? t.src_of[i] : i;
             const double Voli = t.Vol[o];
             const double b11 = t.b11[o], b12 = t.b12[o], b21 = t.b21[o], b22 = t.b22[o];
             const double vxi = s.vx[i];
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(const Clock *clk, Grid g, Phys
     const double xi = s.x[i], yi = s.y[i];
     const int a = s.id[i];
     int cx, cy;
-    cell_of(g, xi, yi, cx, cy);
+    binned_cell(g, s, i, cx, cy);
     int n = 0;
     const int base = MODE ? off[a] : 0;
     auto emit = [&](int b, double dx, double dy, double r2) {

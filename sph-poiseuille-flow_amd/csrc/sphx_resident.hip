@@ -61,23 +61,42 @@ struct sphx_ctx {
     int nf = 0, nw = 0, nt = 0;  // caller's global counts (single GPU: nf particles resident)
     int cap = 0;                 // particle capacity of the device arrays
     int lpp = 1, spg = 2;
-    int cur = 0;                 // which FluidSet holds the current state
-    int64_t step_at_cur0 = 0;
-    bool have_step_outputs = false;
     bool big_scan = false;
-    bool tiled = false;          // LDS-tiled neighbour passes (large particle counts)
+    bool tiled = false;          // LDS-tiled neighbour passes (experimental)
     TileCfg tcfg{};
-    int n_vpart = 0;             // entries of vpart the clock kernel reduces
+    int n_vpart = 0;             // entries of vpart / dpart the clock kernel reduces
     DevBuf<unsigned short> nl16;
     int n_tiles = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
 
+    // Cell grid with a skin: cells are 2h + skin wide, particles are re-binned only every `rebuild_every` steps
+    // ("rebuild" step: 7 launches, "move" step: 5).  Between two builds every sweep is centred on the cell a
+    // particle was binned into, which finds all neighbours while nobody has drifted more than skin/2; the
+    // device clock tracks the largest drift (Clock::drift) and stops the loop before the bound is violated.
+    double skin = 0.0;
+    int rebuild_every = 1;       // interval in force; shrinks on back-to-back forced rebuilds, grows back to
+    int rebuild_every0 = 1;      // ... this configured value, one notch every kRegrowSteps steps
+    int64_t grow_at = 0;         // step index at which the interval takes its next notch back
+    int64_t prov_step = 0;       // step index the next enqueued slot will have if every slot before it executes
+
+    // where the current state lives: state buffers S[cur] (x,y,vx,vy,drho), layout buffers L[lay]
+    // (mass,id,start,cell); `pos` = steps taken since the grid was built.  Derived from the device step count.
+    int cur = 0, lay = 0, pos = 0;
+    int64_t epoch_step = 0;      // step count at which (epoch_cur, epoch_lay, epoch_pos, ...) held
+    int epoch_cur = 0, epoch_lay = 0, epoch_pos = 0, epoch_k = 1;
+    int64_t epoch_grow_at = 0;
+    int epoch_out_lay = 0;
+    int out_lay = 0;             // layout the per-step outputs (rho,p,force,Vol,B) are stored in; when it is not
+                                 // `lay`, tmp.src_of maps current slots to the slots of those outputs
+    int64_t n_forced_rebuilds = 0, last_forced_step = 0;
+    int64_t pending_target = 0;  // step count the sphx_ctx_enqueue_steps calls since the last sync aim for
+    bool have_step_outputs = false;
+
     // storage
-    DevBuf<double> fx_[2], fy_[2], fvx_[2], fvy_[2], fdrho_[2], fmass_[2];
-    DevBuf<int> fid_[2], fstart_[2];
-    DevBuf<double> xn, yn, vxn, vyn, drhon, rho, Vol, rhoh, ph, b11, b12, b21, b22, fpx, fpy, ffx, ffy, rho_out, p_out, vpart;
-    DevBuf<unsigned int> ticket;
+    DevBuf<double> fx_[2], fy_[2], fvx_[2], fvy_[2], fdrho_[2], fmass_[2], fxb_[2], fyb_[2];
+    DevBuf<int> fid_[2], fstart_[2], fcell_[2];
+    DevBuf<double> xn, yn, vxn, vyn, drhon, rho, Vol, rhoh, ph, b11, b12, b21, b22, fpx, fpy, ffx, ffy, rho_out, p_out, vpart, dpart;
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, flags, tile;
     DevBuf<double> wx, wy, wVol, wvx, wvy;
     DevBuf<int> wid, wstart, wrow_any;
@@ -85,19 +104,14 @@ struct sphx_ctx {
     DevBuf<double> tau_part, tau_out;
     Clock *h_clock = nullptr;  // pinned
 
-    FluidSet set[2]{};
     FluidTmp tmp{};
     Walls walls{};
     int n_blocks_particles = 0;  // grid of the LPP kernels (capacity based)
     int n_blocks_flat = 0;       // grid of one-thread-per-particle kernels
 
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    hipGraph_t pgraph = nullptr;       // profiling graph: same steps with event-record nodes
-    hipGraphExec_t pgraph_exec = nullptr;
-    bool pgraph_failed = false;
+    hipGraphExec_t graph_exec[65] = {};  // one replayable graph per rebuild interval (index K), captured on demand
+    int64_t chunk_slots = 128;   // slots enqueued between two host looks at the clock (adaptive, see advance)
     bool profiling = false;
-    bool capturing_profile = false;
     KernelTimer timer;
 
     // pair list held for sphx_neighbor_fetch
@@ -112,18 +126,31 @@ struct sphx_ctx {
     DevBuf<double> kx, ky, kvx, kvy, kdrho, kmass;
     DevBuf<int> kid, counters, n_new;
     SlabPack pack{};
-    int64_t slab_steps_enqueued = 0;
+    int64_t slab_steps_enqueued = 0, slab_step0 = 0;
     // each half-step is captured once per parity (and per buffer set) and replayed: 2 graph launches per step
     // instead of ~14 kernel launches keep the host off the critical path of small slabs
     hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
     const void *slab_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
+    FluidSet view(int q, int l)
+    {
+        return FluidSet{fx_[q].get(), fy_[q].get(), fvx_[q].get(), fvy_[q].get(), fdrho_[q].get(), fmass_[l].get(),
+                        fid_[l].get(), fstart_[l].get(), fcell_[l].get(), skin > 0.0 ? fxb_[l].get() : nullptr,
+                        skin > 0.0 ? fyb_[l].get() : nullptr};
+    }
+    double half_skin() const { return 0.5 * skin; }
+
+    void drop_graph()
+    {
+        for (auto &e : graph_exec) {
+            if (e) (void)hipGraphExecDestroy(e);
+            e = nullptr;
+        }
+    }
+
     ~sphx_ctx()
     {
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        if (pgraph_exec) (void)hipGraphExecDestroy(pgraph_exec);
-        if (pgraph) (void)hipGraphDestroy(pgraph);
+        drop_graph();
         for (auto &h : slab_graph) for (auto &e : h) if (e) (void)hipGraphExecDestroy(e);
         timer.collect();
         timer.drop_graph_events();
@@ -138,37 +165,26 @@ thread_local sphx_ctx *g_search_ctx = nullptr;  // owns the temporary context of
 thread_local sphx_ctx *g_fetch_src = nullptr;   // context whose pair list the next sphx_neighbor_fetch copies out
 
 template <typename K, typename... Args>
-void launch(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, Args... args)
+void launch_s(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, size_t shmem, Args... args)
 {
-    if (c->profiling || c->capturing_profile) {
+    if (c->profiling) {  // eager launch with an event pair (event-record nodes in a replayed graph read 0 on ROCm 7.2)
         KernelTimer::Pending p;
         p.idx = c->timer.index_of(name);
         SPHX_HIP(hipEventCreate(&p.a));
         SPHX_HIP(hipEventCreate(&p.b));
         SPHX_HIP(hipEventRecord(p.a, c->stream));
-        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, args...);
+        hipLaunchKernelGGL(kernel, grid, block, shmem, c->stream, args...);
         SPHX_HIP(hipEventRecord(p.b, c->stream));
-        (c->capturing_profile ? c->timer.graph_evs : c->timer.pending).push_back(p);
+        c->timer.pending.push_back(p);
     } else {
-        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, args...);
+        hipLaunchKernelGGL(kernel, grid, block, shmem, c->stream, args...);
     }
 }
 
 template <typename K, typename... Args>
-void launch_s(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, size_t shmem, Args... args)
+void launch(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, Args... args)
 {
-    if (c->profiling || c->capturing_profile) {
-        KernelTimer::Pending p;
-        p.idx = c->timer.index_of(name);
-        SPHX_HIP(hipEventCreate(&p.a));
-        SPHX_HIP(hipEventCreate(&p.b));
-        SPHX_HIP(hipEventRecord(p.a, c->stream));
-        hipLaunchKernelGGL(kernel, grid, block, shmem, c->stream, args...);
-        SPHX_HIP(hipEventRecord(p.b, c->stream));
-        (c->capturing_profile ? c->timer.graph_evs : c->timer.pending).push_back(p);
-    } else {
-        hipLaunchKernelGGL(kernel, grid, block, shmem, c->stream, args...);
-    }
+    launch_s(c, name, kernel, grid, block, 0, args...);
 }
 
 ReorderArgs reorder_args(const double *const src[6], const int *id_src, const FluidSet &d, int *src_of)
@@ -177,21 +193,25 @@ ReorderArgs reorder_args(const double *const src[6], const int *id_src, const Fl
     ra.nd = 6;
     double *dst[6] = {d.x, d.y, d.vx, d.vy, d.drho, d.mass};
     for (int f = 0; f < 6; ++f) { ra.src[f] = src[f]; ra.dst[f] = dst[f]; }
+    if (d.xb) {  // remember where every particle was when it was binned
+        ra.nd = 8;
+        ra.src[6] = src[0]; ra.dst[6] = d.xb;
+        ra.src[7] = src[1]; ra.dst[7] = d.yb;
+    }
     ra.id_src = id_src;
     ra.id_dst = d.id;
     ra.src_of = src_of;
+    ra.cell_dst = d.cell;
     return ra;
 }
 
-// only: 0 = all four neighbour passes, 1..4 = just density / kgc / forces / continuity (kernel timing)
+// The four neighbour passes on state view `s`, writing the end-of-step state through t.xn/yn/vxn/vyn/drhon.
+// only: 0 = all four, 1..4 = just density / kgc / forces / continuity (kernel timing)
 template <int LPP>
-void launch_physics(sphx_ctx *c, int q, int do_hist, int only = 0, bool fuse_clock = false)
+void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
-    FuseClock fc{};
-    if (fuse_clock) fc = FuseClock{1, c->ticket.get(), c->set[1 - q].start, c->grid.ncells, c->n_vpart};
-    const FluidSet &s = c->set[q];
     if (c->tiled) {
         const TileCfg tc = c->tcfg;
         const dim3 gt(c->grid.ncx * tc.nseg);
@@ -199,42 +219,40 @@ void launch_physics(sphx_ctx *c, int q, int do_hist, int only = 0, bool fuse_clo
         unsigned short *nl = c->nl16.get();
         if (!only || only == 1)
             launch_s(c, "k_density_t", k_density_t<LPP>, gt, bp, 2 * H + 3 * (size_t)(tc.ct + 4) * sizeof(int), clk, q,
-                     c->grid, c->phys, s, c->tmp, c->walls, tc, nl);
+                     c->grid, c->phys, s, t, c->walls, tc, nl);
         if (!only || only == 2)
-            launch_s(c, "k_kgc_t", k_kgc_t<LPP>, gt, bp, 3 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls, tc,
+            launch_s(c, "k_kgc_t", k_kgc_t<LPP>, gt, bp, 3 * H, clk, q, c->grid, c->phys, s, t, c->walls, tc,
                      (const unsigned short *)nl);
         if (!only || only == 3)
-            launch_s(c, "k_forces_t", k_forces_t<LPP>, gt, bp, 11 * H, clk, q, c->grid, c->phys, s, c->tmp, c->walls, tc,
+            launch_s(c, "k_forces_t", k_forces_t<LPP>, gt, bp, 11 * H, clk, q, c->grid, c->phys, s, t, c->walls, tc,
                      (const unsigned short *)nl);
         if (!only || only == 4)
-            launch_s(c, "k_continuity_t", k_continuity_t<LPP>, gt, bp, 5 * H, clk, q, c->grid, c->phys, s, c->tmp,
-                     c->walls, do_hist, tc, (const unsigned short *)nl);
+            launch_s(c, "k_continuity_t", k_continuity_t<LPP>, gt, bp, 5 * H, clk, q, c->grid, c->phys, s, t, c->walls,
+                     do_hist, tc, (const unsigned short *)nl);
         return;
     }
-    if (!only || only == 1) launch(c, "k_density", k_density<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
-    if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
-    if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, c->tmp, c->walls);
-    if (!only || only == 4)
-        launch(c, "k_continuity", k_continuity<LPP>, gp, bp, c->clock.get(), q, c->grid, c->phys, s, c->tmp, c->walls, do_hist, fc);
+    if (!only || only == 1) launch(c, "k_density", k_density<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+    if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+    if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+    if (!only || only == 4) launch(c, "k_continuity", k_continuity<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, do_hist);
 }
 
-void launch_physics_any(sphx_ctx *c, int q, int do_hist, int only = 0, bool fuse_clock = false)
+void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0)
 {
     switch (c->lpp) {
-        case 1: launch_physics<1>(c, q, do_hist, only, fuse_clock); break;
-        case 2: launch_physics<2>(c, q, do_hist, only, fuse_clock); break;
-        case 4: launch_physics<4>(c, q, do_hist, only, fuse_clock); break;
-        case 8: launch_physics<8>(c, q, do_hist, only, fuse_clock); break;
-        case 16: launch_physics<16>(c, q, do_hist, only, fuse_clock); break;
-        case 32: launch_physics<32>(c, q, do_hist, only, fuse_clock); break;
+        case 1: launch_physics<1>(c, q, s, t, do_hist, only); break;
+        case 2: launch_physics<2>(c, q, s, t, do_hist, only); break;
+        case 4: launch_physics<4>(c, q, s, t, do_hist, only); break;
+        case 8: launch_physics<8>(c, q, s, t, do_hist, only); break;
+        case 16: launch_physics<16>(c, q, s, t, do_hist, only); break;
+        case 32: launch_physics<32>(c, q, s, t, do_hist, only); break;
         default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
     }
 }
 
 // exclusive scan of the cell histogram into start_next (three kernels on big grids)
-void launch_cell_scan(sphx_ctx *c, int q, int *start_next)
+void launch_cell_scan(sphx_ctx *c, const Clock *clk, int q, int *start_next)
 {
-    const Clock *clk = c->clock.get();
     if (!c->big_scan) {
         launch(c, "k_scan", k_scan_only, dim3(1), dim3(kScanBlock), clk, q, (const int *)c->count.get(), start_next,
                c->grid.ncells);
@@ -248,10 +266,10 @@ void launch_cell_scan(sphx_ctx *c, int q, int *start_next)
     }
 }
 
-void launch_scatter_reorder(sphx_ctx *c, int q, const double *const src[6], const int *id_src, int *src_of)
+// index -> cell slot, then the gather of the persistent fields into destination view d
+void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const double *const src[6], const int *id_src,
+                            const FluidSet &d, int *src_of)
 {
-    const Clock *clk = c->clock.get();
-    const FluidSet &d = c->set[1 - q];
     const dim3 g1(c->n_blocks_flat), bp(kBlock);
     launch(c, "k_scatter", k_scatter, g1, bp, clk, q, 0, (const int *)c->cellid.get(), c->count.get(), (const int *)d.start,
            c->perm.get());
@@ -259,97 +277,132 @@ void launch_scatter_reorder(sphx_ctx *c, int q, const double *const src[6], cons
            (const int *)c->perm.get(), reorder_args(src, id_src, d, src_of));
 }
 
-// one single-GPU step slot of parity q
-void launch_step(sphx_ctx *c, int q)
+// One single-GPU step slot: state S[q], layout L[l].  rebuild: the step ends with re-binning into S[1-q], L[1-l]
+// (7 launches); otherwise the passes write the new state straight into S[1-q] and the layout stays (5 launches).
+void launch_step(sphx_ctx *c, int q, int l, bool rebuild)
 {
-    // (the last-workgroup clock+scan inside k_continuity measured 25.9 us vs 10.6 + 6.4 us for two launches at
-    // C2 -- 600 agent-scope fences + arrivals cost more than a dispatch -- so it stays off)
-    const bool fuse = false;
-    launch_physics_any(c, q, 1, 0, fuse);
     Clock *clk = c->clock.get();
-    const FluidSet &s = c->set[q];
-    const FluidSet &d = c->set[1 - q];
-    const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
-    if (fuse) {
-        launch_scatter_reorder(c, q, src, s.id, c->tmp.src_of);
+    const FluidSet s = c->view(q, l);
+    const bool track = c->skin > 0.0;
+    const double *dpart = track ? (const double *)c->dpart.get() : nullptr;
+    if (!rebuild) {
+        FluidTmp t = c->tmp;
+        const FluidSet o = c->view(1 - q, l);
+        t.xn = o.x; t.yn = o.y; t.vxn = o.vx; t.vyn = o.vy; t.drhon = o.drho;
+        launch_physics_any(c, q, s, t, 0);
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
+               (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(), (const int *)nullptr,
+               (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin());
         return;
     }
+    launch_physics_any(c, q, s, c->tmp, 1);
+    const FluidSet d = c->view(1 - q, 1 - l);
+    const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(),
-               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr);
+               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr, dpart, 1, c->half_skin());
     } else {
         int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
         launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
                (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(), (const int *)tile_sum,
-               tile_off, c->n_tiles, (const int *)nullptr);
+               tile_off, c->n_tiles, (const int *)nullptr, dpart, 1, c->half_skin());
         launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                (const int *)tile_off, c->grid.ncells, c->n_tiles);
     }
-    launch_scatter_reorder(c, q, src, s.id, c->tmp.src_of);
+    launch_scatter_reorder(c, clk, q, src, s.id, d, c->tmp.src_of);
 }
 
-void capture_steps(sphx_ctx *c, hipGraph_t *g, hipGraphExec_t *e)
+constexpr int64_t kRegrowSteps = 1024;
+
+// The rebuild interval is part of the schedule, so it may only change at step indices that do not depend on
+// when the host happens to look: right after a forced rebuild (a device-side event) and at fixed distances
+// from the last change.  Called before every slot, both when enqueueing and when replaying.
+void policy_before_slot(sphx_ctx *c)
 {
-    SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    try {
-        for (int k = 0; k < c->spg; ++k) launch_step(c, k & 1);
-    } catch (...) {
-        hipGraph_t junk = nullptr;
-        (void)hipStreamEndCapture(c->stream, &junk);
-        if (junk) (void)hipGraphDestroy(junk);
-        throw;
+    if (c->rebuild_every < c->rebuild_every0 && c->prov_step >= c->grow_at) {
+        c->rebuild_every += 1;
+        c->grow_at = c->prov_step + kRegrowSteps;
     }
-    SPHX_HIP(hipStreamEndCapture(c->stream, g));
-    SPHX_HIP(hipGraphInstantiate(e, *g, nullptr, nullptr, 0));
+}
+
+bool slot_rebuilds(const sphx_ctx *c) { return c->pos >= c->rebuild_every - 1; }
+
+// host-side bookkeeping of one executed step
+void track_step(sphx_ctx *c)
+{
+    const bool rebuild = slot_rebuilds(c);
+    c->prov_step += 1;
+    c->out_lay = c->lay;  // outputs are stored in the layout the step ran in; after a rebuild tmp.src_of maps to it
+    c->cur ^= 1;
+    if (rebuild) { c->lay ^= 1; c->pos = 0; }
+    else c->pos += 1;
+}
+
+int graph_slots(const sphx_ctx *c)
+{
+    const int period = 2 * c->rebuild_every;  // (cur, lay, pos) returns to itself after 2K steps
+    return period * std::max(1, c->spg / period);
 }
 
 void build_graph(sphx_ctx *c)
 {
-    if (c->graph_exec) return;
+    const int K = c->rebuild_every, n = graph_slots(c);
+    if (c->graph_exec[K]) return;
     const bool prof = c->profiling;
     c->profiling = false;
-    try { capture_steps(c, &c->graph, &c->graph_exec); } catch (...) { c->profiling = prof; throw; }
-    c->profiling = prof;
-}
-
-// profiling graph: the same step slots with an event-record node on either side of every kernel, so the
-// per-kernel device time is measured in the regime the timed region runs in (graph replay)
-bool build_profile_graph(sphx_ctx *c)
-{
-    if (c->pgraph_exec) return true;
-    if (c->pgraph_failed) return false;
-    const bool prof = c->profiling;
-    c->profiling = false;
-    c->capturing_profile = true;
+    SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     try {
-        capture_steps(c, &c->pgraph, &c->pgraph_exec);
-    } catch (const std::exception &) {
-        (void)hipGetLastError();
-        c->timer.drop_graph_events();
-        c->pgraph_failed = true;
+        for (int j = 0; j < n; ++j) launch_step(c, j & 1, (j / K) & 1, (j % K) == K - 1);
+    } catch (...) {
+        hipGraph_t junk = nullptr;
+        (void)hipStreamEndCapture(c->stream, &junk);
+        if (junk) (void)hipGraphDestroy(junk);
+        c->profiling = prof;
+        throw;
     }
-    c->capturing_profile = false;
     c->profiling = prof;
-    return !c->pgraph_failed;
+    hipGraph_t g = nullptr;
+    SPHX_HIP(hipStreamEndCapture(c->stream, &g));
+    const hipError_t e = hipGraphInstantiate(&c->graph_exec[K], g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    SPHX_HIP(e);
 }
 
-// enqueue `slots` step slots starting at parity c->cur (slots that find run[q]==0 are no-ops)
+// Enqueue `slots` step slots from the current (cur, lay, pos); slots that find run[q]==0 are no-ops.  Whole
+// graphs are replayed whenever the state is the one the graph was captured from, single slots are launched
+// eagerly otherwise.  The host copies of cur/lay/pos advance as if every slot executed; read_clock() recomputes
+// them from the executed step count.
 void enqueue_slots(sphx_ctx *c, int64_t slots)
 {
-    int q = c->cur;
     int64_t left = slots;
-    if (left > 0 && q == 1) { launch_step(c, 1); q = 0; --left; }
-    // profiling: eager launches with an event pair around every kernel (event-record nodes inside a
-    // replayed hipGraph report zero elapsed time on ROCm 7.2, so the graph regime cannot be timed per kernel)
-    if (!c->profiling && left >= c->spg) {
-        build_graph(c);
-        while (left >= c->spg) { SPHX_HIP(hipGraphLaunch(c->graph_exec, c->stream)); left -= c->spg; }
+    while (left > 0) {
+        policy_before_slot(c);
+        const int per_graph = graph_slots(c);
+        const bool steady = c->rebuild_every == c->rebuild_every0 || c->prov_step + per_graph <= c->grow_at;
+        if (!c->profiling && steady && c->cur == 0 && c->lay == 0 && c->pos == 0 && left >= per_graph) {
+            build_graph(c);
+            SPHX_HIP(hipGraphLaunch(c->graph_exec[c->rebuild_every], c->stream));
+            left -= per_graph;  // back at (0,0,0); the last slot was a rebuild out of layout 1
+            c->prov_step += per_graph;
+            c->out_lay = 1;
+            continue;
+        }
+        launch_step(c, c->cur, c->lay, slot_rebuilds(c));
+        track_step(c);
+        --left;
     }
-    while (left > 0) { launch_step(c, q); q ^= 1; --left; }
     SPHX_HIP(hipGetLastError());
+}
+
+void set_epoch(sphx_ctx *c)
+{
+    c->epoch_step = c->h_clock->step;
+    c->epoch_cur = c->cur; c->epoch_lay = c->lay; c->epoch_pos = c->pos; c->epoch_out_lay = c->out_lay;
+    c->epoch_k = c->rebuild_every; c->epoch_grow_at = c->grow_at;
+    c->prov_step = c->epoch_step;
 }
 
 void read_clock(sphx_ctx *c)
@@ -357,9 +410,68 @@ void read_clock(sphx_ctx *c)
     SPHX_HIP(hipMemcpyAsync(c->h_clock, c->clock.get(), sizeof(Clock), hipMemcpyDeviceToHost, c->stream));
     SPHX_HIP(hipStreamSynchronize(c->stream));
     c->timer.collect();
-    const int64_t executed = (int64_t)c->h_clock->step - c->step_at_cur0;
-    if (executed > 0) c->have_step_outputs = true;
-    c->cur = (int)(executed & 1);
+    // replay the bookkeeping of the steps that really executed since the last read
+    const int64_t executed = (int64_t)c->h_clock->step - c->epoch_step;
+    c->cur = c->epoch_cur; c->lay = c->epoch_lay; c->pos = c->epoch_pos; c->out_lay = c->epoch_out_lay;
+    c->rebuild_every = c->epoch_k; c->grow_at = c->epoch_grow_at; c->prov_step = c->epoch_step;
+    if (executed > 0) {
+        int64_t left = executed;
+        while (left > 0) {
+            policy_before_slot(c);
+            if (c->rebuild_every == c->rebuild_every0 && left > 4 * c->rebuild_every) {
+                // steady interval: (cur, lay, pos) repeats every 2K steps -> skip whole periods
+                const int64_t period = 2 * c->rebuild_every, skip = ((left - 1) / period - 1) * period;
+                if (skip > 0) { c->prov_step += skip; left -= skip; }
+            }
+            track_step(c);
+            --left;
+        }
+        c->have_step_outputs = true;
+    }
+    set_epoch(c);
+}
+
+// Re-bin the current state into the other buffers without taking a step: the device stopped the loop because
+// some particle drifted further than skin/2 from where it was binned.  Happens only when the flow is faster than
+// the skin was sized for; the rebuild interval shrinks by one when it happens in back-to-back cycles.
+void forced_rebuild(sphx_ctx *c)
+{
+    const int q = c->cur, l = c->lay;
+    if (c->have_step_outputs && c->out_lay != l)
+        throw Error(SPHX_ERR_STATE, "SPHX:Ctx:rebuild", "internal: forced rebuild straight after a rebuild step");
+    const FluidSet s = c->view(q, l), d = c->view(1 - q, 1 - l);
+    hipStream_t st = c->stream;
+    const int n = c->h_clock->n;
+    const dim3 g1(c->n_blocks_flat), bp(kBlock);
+    const bool prof = c->profiling;
+    c->profiling = false;
+    hipLaunchKernelGGL(k_bin, g1, bp, 0, st, (const Clock *)nullptr, 0, c->grid, n, (const double *)s.x, (const double *)s.y,
+                       c->cellid.get(), c->count.get());
+    launch_cell_scan(c, nullptr, 0, d.start);
+    const double *src[6] = {s.x, s.y, s.vx, s.vy, s.drho, s.mass};
+    hipLaunchKernelGGL(k_scatter, g1, bp, 0, st, (const Clock *)nullptr, 0, n, (const int *)c->cellid.get(), c->count.get(),
+                       (const int *)d.start, c->perm.get());
+    // src_of: new slot -> slot of the layout the last step's outputs (rho, p, force, Vol, B) are stored in
+    hipLaunchKernelGGL(k_reorder, g1, bp, 0, st, (const Clock *)nullptr, 0, n, (const int *)c->cellid.get(),
+                       (const int *)d.start, (const int *)c->perm.get(), reorder_args(src, s.id, d, c->tmp.src_of));
+    hipLaunchKernelGGL(k_rebinned, dim3(1), dim3(1), 0, st, c->clock.get());
+    c->profiling = prof;
+    SPHX_HIP(hipGetLastError());
+    c->cur = 1 - q; c->lay = 1 - l; c->pos = 0;  // out_lay stays l
+    c->h_clock->need_rebuild = 0;
+    c->h_clock->drift = 0.0;
+    // Single particles now and then jump by a few tenths of h in one step (transport shift next to a void), which
+    // costs one host round trip here; only stops in back-to-back rebuild cycles mean the interval is too long.
+    const int64_t now = c->h_clock->step;
+    if (c->n_forced_rebuilds > 0 && now - c->last_forced_step <= 2 * (int64_t)c->rebuild_every && c->rebuild_every > 1)
+        c->rebuild_every -= 1;
+    c->grow_at = now + kRegrowSteps;
+    if (getenv("SPHX_DEBUG"))
+        fprintf(stderr, "sphx: forced rebuild #%lld at step %lld, drift bound hit; interval now %d (configured %d)\n",
+                (long long)c->n_forced_rebuilds + 1, (long long)now, c->rebuild_every, c->rebuild_every0);
+    c->last_forced_step = now;
+    c->n_forced_rebuilds += 1;
+    set_epoch(c);
 }
 
 void fill_status(sphx_ctx *c, sphx_status *st)
@@ -425,9 +537,8 @@ void ctx_alloc(sphx_ctx *c, int cap)
     for (int k = 0; k < 2; ++k) {
         c->fx_[k].alloc(cap); c->fy_[k].alloc(cap); c->fvx_[k].alloc(cap); c->fvy_[k].alloc(cap);
         c->fdrho_[k].alloc(cap); c->fmass_[k].alloc(cap); c->fid_[k].alloc(cap);
-        c->fstart_[k].alloc((size_t)g.ncells + 1);
-        c->set[k] = FluidSet{c->fx_[k].get(), c->fy_[k].get(), c->fvx_[k].get(), c->fvy_[k].get(), c->fdrho_[k].get(),
-                             c->fmass_[k].get(), c->fid_[k].get(), c->fstart_[k].get()};
+        c->fstart_[k].alloc((size_t)g.ncells + 1); c->fcell_[k].alloc(cap);
+        if (c->skin > 0.0) { c->fxb_[k].alloc(cap); c->fyb_[k].alloc(cap); }
     }
     DevBuf<double> *dbl[] = {&c->xn, &c->yn, &c->vxn, &c->vyn, &c->drhon, &c->rho, &c->Vol, &c->rhoh, &c->ph, &c->b11,
                              &c->b12, &c->b21, &c->b22, &c->fpx, &c->fpy, &c->ffx, &c->ffy, &c->rho_out, &c->p_out};
@@ -448,6 +559,8 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->n_vpart = c->tiled ? g.ncx * c->tcfg.nseg : c->n_blocks_particles;
     c->vpart.alloc(c->n_vpart);
     c->vpart.zero(c->stream);
+    c->dpart.alloc(c->n_vpart);
+    c->dpart.zero(c->stream);
     c->cellid.alloc(cap); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(cap); c->src_of.alloc(cap);
     c->count.zero(c->stream);
     const int nl_cap = nl_cap_for(c->lpp);
@@ -458,21 +571,19 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->nl_cnt.zero(c->stream);
     c->flags.alloc(1);
     c->flags.zero(c->stream);
-    c->ticket.alloc(1);
-    c->ticket.zero(c->stream);
     c->big_scan = g.ncells > kBigScanCells;
     c->n_tiles = (int)div_up((size_t)g.ncells, kScanBlock);
     c->tile.alloc(2 * ((size_t)c->n_tiles + 1));
     c->tmp = FluidTmp{c->xn.get(), c->yn.get(), c->vxn.get(), c->vyn.get(), c->drhon.get(), c->rho.get(), c->Vol.get(),
                       c->rhoh.get(), c->ph.get(), c->b11.get(), c->b12.get(), c->b21.get(), c->b22.get(), c->fpx.get(),
                       c->fpy.get(), c->ffx.get(), c->ffy.get(), c->rho_out.get(), c->p_out.get(), c->cellid.get(),
-                      c->count.get(), c->perm.get(), c->src_of.get(), c->vpart.get(), c->nl_idx.get(), c->nl_cnt.get(),
+                      c->count.get(), c->perm.get(), c->src_of.get(), c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(),
                       c->flags.get(), c->tile.get(), (int)stride, nl_cap};
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
 
-// upload n fluid particles (host SoA) and sort them into set[0]
+// upload n fluid particles (host SoA) and sort them into state 0 / layout 0
 void upload_fluid(sphx_ctx *c, int n, const double *hx, const double *hy, const double *hvx, const double *hvy,
                   const double *hdrho, const double *hmass, const int *hid, bool wrap)
 {
@@ -486,8 +597,9 @@ void upload_fluid(sphx_ctx *c, int n, const double *hx, const double *hy, const 
         if (wrap) hipLaunchKernelGGL(k_wrap_x, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, c->xn.get(), c->prm.DL);
     }
     const double *src[6] = {c->xn.get(), c->yn.get(), c->vxn.get(), c->vyn.get(), c->drhon.get(), c->fmass_[1].get()};
-    initial_sort(c, c->grid, n, c->xn.get(), c->yn.get(), c->cellid.get(), c->count.get(), c->set[0].start, c->perm.get(),
-                 reorder_args(src, c->fid_[1].get(), c->set[0], nullptr));
+    const FluidSet d = c->view(0, 0);
+    initial_sort(c, c->grid, n, c->xn.get(), c->yn.get(), c->cellid.get(), c->count.get(), d.start, c->perm.get(),
+                 reorder_args(src, c->fid_[1].get(), d, nullptr));
     SPHX_HIP(hipStreamSynchronize(s));  // host staging vectors of the caller may die after this
 }
 
@@ -515,7 +627,7 @@ void upload_walls(sphx_ctx *c, int nw, const double *hx, const double *hy, const
     const double *src[5] = {tx.get(), ty.get(), tV.get(), tvx.get(), tvy.get()};
     double *dst[5] = {c->wx.get(), c->wy.get(), c->wVol.get(), c->wvx.get(), c->wvy.get()};
     for (int f = 0; f < 5; ++f) { ra.src[f] = src[f]; ra.dst[f] = dst[f]; }
-    ra.id_src = tid.get(); ra.id_dst = c->wid.get(); ra.src_of = nullptr;
+    ra.id_src = tid.get(); ra.id_dst = c->wid.get(); ra.src_of = nullptr; ra.cell_dst = nullptr;
     initial_sort(c, g, nw, tx.get(), ty.get(), tcell.get(), tcount.get(), c->wstart.get(), tperm.get(), ra);
     hipLaunchKernelGGL(k_row_any, dim3(div_up(g.ncy, 64)), dim3(64), 0, s, g, (const int *)c->wstart.get(), c->wrow_any.get());
     SPHX_HIP(hipGetLastError());
@@ -531,14 +643,16 @@ void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
     Clock k{};
     k.t = t0; k.dt = 0.0; k.dt_last = 0.0; k.t_target = t0; k.t_end = c->prm.t_end; k.vmax = 0.0;
     k.step = step0; k.steps_left = -1; k.run[0] = 0; k.run[1] = 0; k.status = 0; k.n = n;
+    k.drift = 0.0; k.need_rebuild = 0;
     *c->h_clock = k;
     SPHX_HIP(hipMemcpyAsync(c->clock.get(), c->h_clock, sizeof(Clock), hipMemcpyHostToDevice, s));
     SPHX_HIP(hipStreamSynchronize(s));
-    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, s, c->clock.get(), c->grid, (const double *)c->set[0].x,
-                       (const double *)c->set[0].vx, (const double *)c->set[0].vy, (double *)nullptr);
+    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, s, c->clock.get(), c->grid, (const double *)c->fx_[0].get(),
+                       (const double *)c->fvx_[0].get(), (const double *)c->fvy_[0].get(), (double *)nullptr);
     SPHX_HIP(hipGetLastError());
-    c->cur = 0;
-    c->step_at_cur0 = step0;
+    c->cur = 0; c->lay = 0; c->pos = 0; c->out_lay = 0;
+    set_epoch(c);
+    c->pending_target = step0;
 }
 
 void common_checks(const sphx_params *prm, int n_fluid, int n_total)
@@ -575,10 +689,33 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     const size_t ntz = (size_t)n_total;
     const double *px = pos, *py = pos + ntz;
 
-    // grid: exact periodic tiling in x (cells >= 2h), 2h rows in y over fluid + wall extent
+    c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
+    if (prm->lanes_per_particle <= 0 && prm->reserved > 0) c->lpp = std::max(c->lpp, 2);
+    check_lpp(c->lpp);
+    c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 16;
+    if (c->spg & 1) c->spg += 1;
+
+    // Rebuild interval K and the cell skin that pays for it.  One step moves a particle by at most
+    // dt*v <= 0.25 h v/(c_f+v); the reference sets c_f = 10 U_max, so v/c_f stays near 0.1-0.15 (0.033 h per
+    // step; measured 0.017 h at c_f = 15) plus transport shifts of single particles (up to ~0.09 h measured):
+    // the skin covers K-1 steps of 0.035 h.  If a flow outruns it the device clock stops the loop and
+    // forced_rebuild() takes over, so this is a speed heuristic, never a correctness assumption.
+    // Measured (MI355X, us/step, K=1 -> K=5): 4.8 k particles 47.5 -> 37.5 (launch-bound: 7 -> 5 launches per
+    // step), 60 k 93.9 -> 80.2, 0.5 M 343 -> 316, 6 M 4101 -> 3907 (the wider cells lengthen the candidate sweeps
+    // by ~10 %, the scatter/reorder kernels run on every fifth step only).
+    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : 5;
+    if (prm->reserved > 0) K = 1;  // the LDS-tiled kernels bin by position
+    const double d_step = 0.035 * prm->h;
+    double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
+    if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
+    c->rebuild_every = K;
+    c->rebuild_every0 = K;
+    c->skin = skin;
+
+    // grid: exact periodic tiling in x (cells >= 2h + skin), rows of 2h + skin in y over fluid + wall extent
     double y_min, y_max;
     y_extent(py, n_total, y_min, y_max);
-    const double cs = 2.0 * prm->h;
+    const double cs = 2.0 * prm->h + skin;
     Grid g{};
     g.ncx = (int)std::floor(prm->DL / cs);
     require(g.ncx >= 3, "SPH:Neighbor:param", "device path needs DL >= 6h (three periodic cell columns).");
@@ -597,12 +734,6 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     c->grid = g;
     c->phys = make_phys(prm);
 
-    c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
-    if (prm->lanes_per_particle <= 0 && prm->reserved > 0) c->lpp = std::max(c->lpp, 2);
-    check_lpp(c->lpp);
-    c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 16;
-    if (c->spg & 1) c->spg += 1;
-
     SPHX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     SPHX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_clock), sizeof(Clock), hipHostMallocDefault));
     ctx_alloc(c, nf);
@@ -620,7 +751,7 @@ void emit_pairs(sphx_ctx *c, bool fill)
     const int nf = c->nf;
     hipStream_t s = c->stream;
     DevBuf<int> cnt(nf), off((size_t)nf + 1);
-    const FluidSet &fs = c->set[c->cur];
+    const FluidSet fs = c->view(c->cur, c->lay);
     const Clock *clk = c->clock.get();
     const dim3 g1(div_up(nf, kBlock)), b1(kBlock);
     hipLaunchKernelGGL(k_pairs<0>, g1, b1, 0, s, clk, c->grid, c->phys, fs, c->walls, cnt.get(), (const int *)nullptr,
@@ -691,22 +822,28 @@ SPHX_EXPORT int sphx_ctx_advance(sphx_ctx *c, double t_target, int64_t max_steps
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     require(!c->is_slab, "SPHX:Ctx:slab", "slab contexts are advanced with sphx_slab_compute/finish");
+    read_clock(c);  // steps enqueued with sphx_ctx_enqueue_steps may still be in flight
     for (int guard = 0; guard < 1000000; ++guard) {
+        if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
         hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target,
                            (long long)max_steps, c->cur, (const double *)nullptr);
         // how many slots this call needs, from the unclipped dt; over-provision to whole graphs when unlimited
         const Clock &k = *c->h_clock;
         const double dt_est = host_dt_unclipped(c, k.vmax);
         double want = std::ceil(std::max(0.0, std::min(t_target, k.t_end) - k.t) / std::max(dt_est, 1e-12)) + 1.0;
-        want = std::min(want, 4096.0);
+        // Slots behind a stop (target reached, stale grid) are empty launches, ~10 us each: look at the clock
+        // often while the device keeps stopping for forced rebuilds, rarely (4096 slots) once it runs through.
+        want = std::min(want, (double)c->chunk_slots);
         int64_t slots = (int64_t)want;
+        const int per_graph = graph_slots(c);
         if (max_steps > 0 && slots >= max_steps) slots = max_steps;  // exact: no no-op slots
-        else if (!c->profiling && slots > c->spg) slots = ((slots + c->spg - 1) / c->spg) * c->spg;
+        else if (!c->profiling && slots > per_graph) slots = ((slots + per_graph - 1) / per_graph) * per_graph;
         if (slots < 1) slots = 1;
         const int64_t step_before = c->h_clock->step;
         enqueue_slots(c, slots);
         read_clock(c);
         const int64_t executed = c->h_clock->step - step_before;
+        c->chunk_slots = c->h_clock->need_rebuild ? 64 : std::min<int64_t>(4096, 2 * c->chunk_slots);
         if (max_steps > 0) {
             max_steps -= executed;
             if (max_steps <= 0) break;
@@ -715,6 +852,7 @@ SPHX_EXPORT int sphx_ctx_advance(sphx_ctx *c, double t_target, int64_t max_steps
         if (!(c->h_clock->t < t_target - 1e-12)) break;
         if (!(c->h_clock->t < c->h_clock->t_end - 1e-12)) break;
     }
+    c->pending_target = c->h_clock->step;
     fill_status(c, status);
     throw_on_status(c);
     return SPHX_OK;
@@ -727,10 +865,13 @@ SPHX_EXPORT int sphx_ctx_enqueue_steps(sphx_ctx *c, int64_t n_steps)
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     require(!c->is_slab, "SPHX:Ctx:slab", "slab contexts are advanced with sphx_slab_compute/finish");
     require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
+    // no host sync here: if an earlier batch stopped early (end time, status, stale grid) the loop condition is
+    // still false when k_prepare re-evaluates it, so every slot of this batch is a no-op; sphx_ctx_sync sorts
+    // out the grid and takes the steps that are still owed
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end,
                        (long long)n_steps, c->cur, (const double *)nullptr);
     enqueue_slots(c, n_steps);
-    c->cur = (int)((c->cur + n_steps) & 1);  // provisional; read_clock() recomputes from the device step count
+    c->pending_target = std::max<int64_t>(c->pending_target, c->h_clock->step) + n_steps;
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -741,6 +882,24 @@ SPHX_EXPORT int sphx_ctx_sync(sphx_ctx *c, sphx_status *status)
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     require(!c->is_slab, "SPHX:Ctx:slab", "use sphx_slab_sync on a slab context");
     read_clock(c);
+    for (int guard = 0; guard < 1000000; ++guard) {
+        const Clock &k = *c->h_clock;
+        const int64_t owed = c->pending_target - (int64_t)k.step;
+        if (!(k.status == 0 && owed > 0 && k.t < k.t_end - 1e-12)) break;
+        if (k.need_rebuild) {
+            forced_rebuild(c);
+            c->chunk_slots = 64;
+        }
+        // the batch stopped at a stale grid: take the steps still owed, in chunks (slots behind another stop
+        // would be empty launches)
+        const int64_t n = std::min(owed, c->chunk_slots);
+        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end, (long long)n,
+                           c->cur, (const double *)nullptr);
+        enqueue_slots(c, n);
+        read_clock(c);
+        if (!c->h_clock->need_rebuild) c->chunk_slots = std::min<int64_t>(4096, 2 * c->chunk_slots);
+    }
+    c->pending_target = c->h_clock->step;
     fill_status(c, status);
     throw_on_status(c);
     return SPHX_OK;
@@ -759,8 +918,8 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
         throw Error(SPHX_ERR_STATE, "SPHX:Ctx:download", "rho/p/force/Vol/B exist only after at least one step");
     const int nf = c->nf, nw = c->nw, nt = c->nt;
     hipStream_t s = c->stream;
-    const FluidSet &fs = c->set[c->cur];
-    const int *id_old = c->set[1 - c->cur].id;  // ordering the step outputs are stored in
+    const FluidSet fs = c->view(c->cur, c->lay);
+    const int *id_old = c->fid_[c->out_lay].get();  // ordering the step outputs are stored in
     DevBuf<double> stage((size_t)4 * nt);
     const dim3 gf(div_up(nf, kBlock)), gw(div_up(std::max(nw, 1), kBlock)), b(kBlock);
     auto col = [&](int cidx) { return stage.get() + (size_t)cidx * nt; };
@@ -801,14 +960,15 @@ SPHX_EXPORT int sphx_ctx_monitor(sphx_ctx *c, double *tau_bottom, double *tau_to
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     require(!c->is_slab, "SPHX:Ctx:slab", "monitors are not available on a slab context");
     read_clock(c);
+    if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);  // the pair sweeps need valid bins
     hipStream_t s = c->stream;
-    const FluidSet &fs = c->set[c->cur];
+    const FluidSet fs = c->view(c->cur, c->lay);
     if (tau_bottom || tau_top) {
         if (!c->have_step_outputs)
             throw Error(SPHX_ERR_STATE, "SPHX:Ctx:monitor", "wall shear needs Vol/B of a completed step");
         const int nblk = c->n_blocks_flat;
         hipLaunchKernelGGL(k_wall_shear, dim3(nblk), dim3(kBlock), 0, s, (const Clock *)c->clock.get(), c->grid, c->phys, fs,
-                           c->tmp, c->walls, c->tau_part.get());
+                           c->tmp, c->walls, c->out_lay != c->lay ? 1 : 0, c->tau_part.get());
         hipLaunchKernelGGL(k_tau_final, dim3(1), dim3(kScanBlock), 0, s, nblk, (const double *)c->tau_part.get(),
                            c->phys.DL, c->tau_out.get());
         double h[2];
@@ -832,6 +992,7 @@ SPHX_EXPORT int sphx_ctx_neighbor_list(sphx_ctx *c, size_t *n_pairs)
     require(c != nullptr && n_pairs != nullptr, "SPHX:Ctx:null", "ctx / n_pairs must not be NULL");
     require(!c->is_slab, "SPHX:Ctx:slab", "pair lists are not available on a slab context");
     read_clock(c);
+    if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
     emit_pairs(c, true);
     *n_pairs = c->pl_n;
     g_fetch_src = c;
@@ -850,6 +1011,7 @@ SPHX_EXPORT int sphx_neighbor_search(const double *pos, int n_fluid, int n_total
         sphx_params prm{};
         prm.DL = DL; prm.DH = 1.0; prm.dp = h / 1.3; prm.h = h; prm.rho0 = 1.0; prm.mu = 1.0; prm.c_f = 1.0; prm.p0 = 1.0;
         prm.inv_sigma0 = 1.0; prm.gravity_g = 0.0; prm.transport_coeff = 0.0; prm.t_end = 0.0; prm.lanes_per_particle = 1;
+        prm.rebuild_every = 1;
         const size_t nt = (size_t)n_total;
         std::vector<double> zeros2(2 * nt, 0.0), ones(nt, 1.0);
         c = new sphx_ctx();
@@ -935,6 +1097,19 @@ SPHX_EXPORT int sphx_ctx_info(sphx_ctx *c, int *n_fluid, int *n_wall, int *n_cel
     if (n_wall) *n_wall = c->nw;
     if (n_cell_x) *n_cell_x = c->grid.ncx;
     if (n_cell_y) *n_cell_y = c->grid.ncy;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_ctx_grid_policy(sphx_ctx *c, int *rebuild_every, double *skin, int64_t *forced_rebuilds,
+                                     double *drift)
+{
+    SPHX_TRY
+    require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    if (rebuild_every) *rebuild_every = c->rebuild_every;
+    if (skin) *skin = c->skin;
+    if (forced_rebuilds) *forced_rebuilds = c->n_forced_rebuilds;
+    if (drift) *drift = c->h_clock->drift;
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -1062,6 +1237,7 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     p.keep_cap = cap;
     c->pack = p;
     init_clock(c, n_local, t0, step0);
+    c->slab_step0 = step0;
     read_clock(c);
 }
 
@@ -1133,7 +1309,7 @@ SPHX_EXPORT int sphx_slab_local_vmax(sphx_ctx *c, double *vmax_dev)
 {
     SPHX_TRY
     require(c != nullptr && c->is_slab && vmax_dev != nullptr, "SPHX:Slab:ctx", "not a slab context");
-    const FluidSet &fs = c->set[c->cur];
+    const FluidSet fs = c->view(c->cur, c->cur);
     hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, c->stream, c->clock.get(), c->grid, (const double *)fs.x,
                        (const double *)fs.vx, (const double *)fs.vy, vmax_dev);
     SPHX_HIP(hipGetLastError());
@@ -1161,13 +1337,13 @@ SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *se
     const int q = c->cur;
     const Clock *clk = c->clock.get();
     auto body = [&]() {
-        launch_physics_any(c, q, 0);
+        launch_physics_any(c, q, c->view(q, q), c->tmp, 0);
         launch(c, "k_vmax_reduce", k_vmax_reduce, dim3(1), dim3(kScanBlock), clk, q, c->n_vpart,
                (const double *)c->vpart.get(), vmax_local_dev);
         SlabPack p = c->pack;
         p.send_l = send_left_dev;
         p.send_r = send_right_dev;
-        launch(c, "k_slab_pack", k_slab_pack, dim3(c->n_blocks_flat), dim3(kBlock), clk, q, c->grid, c->set[q], c->tmp, p);
+        launch(c, "k_slab_pack", k_slab_pack, dim3(c->n_blocks_flat), dim3(kBlock), clk, q, c->grid, c->view(q, q), c->tmp, p);
         launch(c, "k_slab_seal", k_slab_seal, dim3(1), dim3(1), clk, q, p);
     };
     const void *key[3] = {send_left_dev, send_right_dev, vmax_local_dev};
@@ -1193,12 +1369,13 @@ SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const
         // kernels of this slot still test run[q], and from here on clk->n is the new particle count.
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
                vmax_global_dev, (const int *)c->flags.get(), (const int *)nullptr, (int *)nullptr, 0,
-               (const int *)c->n_new.get());
+               (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0);
         launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, q, c->grid, 0, (const double *)c->kx.get(),
                (const double *)c->ky.get(), c->cellid.get(), c->count.get());
-        launch_cell_scan(c, q, c->set[1 - q].start);
+        const FluidSet d = c->view(1 - q, 1 - q);
+        launch_cell_scan(c, clk, q, d.start);
         const double *src[6] = {c->kx.get(), c->ky.get(), c->kvx.get(), c->kvy.get(), c->kdrho.get(), c->kmass.get()};
-        launch_scatter_reorder(c, q, src, c->kid.get(), nullptr);
+        launch_scatter_reorder(c, clk, q, src, c->kid.get(), d, nullptr);
         launch(c, "k_slab_reset", k_slab_reset, dim3(1), dim3(1), (const Clock *)clk, q, c->counters.get());
     };
     const void *key[3] = {recv_left_dev, recv_right_dev, vmax_global_dev};
@@ -1219,7 +1396,7 @@ SPHX_EXPORT int sphx_slab_sync(sphx_ctx *c, sphx_status *status)
     SPHX_HIP(hipStreamSynchronize(c->stream));
     c->timer.collect();
     fill_status(c, status);
-    const int64_t executed = (int64_t)c->h_clock->step - c->step_at_cur0;
+    const int64_t executed = (int64_t)c->h_clock->step - c->slab_step0;
     throw_on_status(c);
     if (executed != c->slab_steps_enqueued)
         throw Error(SPHX_ERR_STATE, "SPHX:Slab:overrun", "a slab step was enqueued after the loop had stopped");
@@ -1239,7 +1416,7 @@ SPHX_EXPORT int sphx_slab_snapshot(sphx_ctx *c, int capacity, int *n, double *x,
     const int m = c->h_clock->n;
     *n = m;
     require(capacity >= m, "SPHX:Slab:capacity", "snapshot arrays are too short");
-    const FluidSet &fs = c->set[c->cur];
+    const FluidSet fs = c->view(c->cur, c->cur);
     hipStream_t s = c->stream;
     auto dl = [&](const void *src, void *dst, size_t bytes) {
         if (dst && m) SPHX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
@@ -1273,6 +1450,7 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     else if (n == "k_continuity" || n == "k_continuity_t") only = 4;
     require(only != 0, "SPHX:Ctx:kernel", "time_kernel knows k_density, k_kgc, k_forces, k_continuity");
     read_clock(c);
+    if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
     const bool prof = c->profiling;
     c->profiling = false;
     hipGraph_t g = nullptr;
@@ -1282,9 +1460,10 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         // arm run[cur] so the kernels execute; no step slot follows, so the clock does not advance
         hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end, (long long)1,
                            c->cur, (const double *)nullptr);
-        launch_physics_any(c, c->cur, 0, 0);  // make every temporary the timed kernel reads valid
+        const FluidSet fs = c->view(c->cur, c->lay);
+        launch_physics_any(c, c->cur, fs, c->tmp, 0, 0);  // make every temporary the timed kernel reads valid
         SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, 0, only);
+        for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, fs, c->tmp, 0, only);
         SPHX_HIP(hipStreamEndCapture(c->stream, &g));
         SPHX_HIP(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
         SPHX_HIP(hipGraphLaunch(e, c->stream));  // warm

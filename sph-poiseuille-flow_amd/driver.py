@@ -40,6 +40,7 @@ class RunResult:
     tau_bottom: float = 0.0
     tau_top: float = 0.0
     tau_target: float = 0.0
+    grid_policy: dict = field(default_factory=dict)  # resident engine: rebuild interval, skin, forced rebuilds
 
     @property
     def particle_steps_per_s(self):
@@ -62,7 +63,8 @@ def periodic_bounding(pos, n_fluid, DL):
     return pos
 
 
-def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_particle=0, steps_per_graph=0):
+def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_particle=0, steps_per_graph=0,
+        rebuild_every=0):
     """Run to prm.t_end and return the final profile and L2 (SPH_Poiseuille.m:246-307 + postprocess :42)."""
     parts = init_particles(prm) if parts is None else parts
     nf, nt = parts["n_fluid"], parts["n_total"]
@@ -72,10 +74,12 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
     _, u0 = compute_mid_channel_profile(parts["pos"][:nf], parts["vel"][:nf, 0], prm.DL, prm.DH, mid_x, mid_hw, n_bins)
     mid_profiles.append(u0)
     tau_b = tau_t = 0.0
+    policy = {}
     t0 = time.perf_counter()
     if engine == "resident":
         ctx = capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"],
-                           parts["wall_vel"], lanes_per_particle=lanes_per_particle, steps_per_graph=steps_per_graph)
+                           parts["wall_vel"], lanes_per_particle=lanes_per_particle, steps_per_graph=steps_per_graph,
+                           rebuild_every=rebuild_every)
         t, step = 0.0, 0
         try:
             while t < prm.t_end - 1e-12:
@@ -98,6 +102,7 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
             tau_b, tau_t, _ = ctx.monitor(tau=True)
             d = ctx.download(fields=("pos", "vel"))
             pos, vel = d["pos"], d["vel"]
+            policy = ctx.grid_policy()
         finally:
             ctx.close()
     elif engine == "mex":
@@ -146,4 +151,4 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
     return RunResult(prm=prm, n_fluid=nf, n_total=nt, t=t, steps=int(step), wall_seconds=wall, pos=pos, vel=vel,
                      y_mid=y_mid, u_mean=u_mean, u_exact=u_exact, L2_error=l2_error(u_mean, u_exact),
                      profile_times=profile_times, mid_profile_u=mid_profiles, tau_bottom=tau_b, tau_top=tau_t,
-                     tau_target=prm.gravity_g * prm.rho0 * prm.DH / 2)
+                     tau_target=prm.gravity_g * prm.rho0 * prm.DH / 2, grid_policy=policy)

@@ -20,11 +20,11 @@ def main():
     res = pkg.driver.run(prm, log=lambda s: print(s, flush=True))
     out = dict(name=name, n_total=res.n_total, steps=res.steps, t=res.t, wall_seconds=res.wall_seconds, L2=res.L2_error,
                particle_steps_per_s=res.particle_steps_per_s, tau_bottom=res.tau_bottom, tau_top=res.tau_top,
-               tau_target=res.tau_target, u_mean=np.nan_to_num(res.u_mean).tolist(), u_exact=res.u_exact.tolist())
+               tau_target=res.tau_target, grid_policy=res.grid_policy, u_mean=np.nan_to_num(res.u_mean).tolist(), u_exact=res.u_exact.tolist())
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"longrun_{name}_{t_end:g}s.json"), "w") as f:
         json.dump(out, f)
-    print({k: out[k] for k in ("name", "n_total", "steps", "wall_seconds", "L2", "particle_steps_per_s", "tau_bottom", "tau_top")})
+    print({k: out[k] for k in ("name", "n_total", "steps", "wall_seconds", "L2", "particle_steps_per_s", "tau_bottom", "tau_top", "grid_policy")})
 
 
 if __name__ == "__main__":

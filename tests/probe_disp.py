@@ -1,0 +1,26 @@
+"""Manual probe (not a test): largest drift from the binning positions, step by step, for a start from rest
+(lattice) and for the developed start of bench.py.  python tests/probe_disp.py"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("sph-poiseuille-flow_amd")
+capi, cfg, geo = pkg.capi, pkg.config, pkg.geometry
+import bench
+for wl in ("C2", "C3"):
+    for start in ("lattice", "developed"):
+        name, kw = bench.parse_workload(wl)
+        prm = cfg.params_from_values(end_time=1e9, **kw)
+        parts = geo.init_particles(prm)
+        pos, vel = (parts["pos"], parts["vel"]) if start == "lattice" else geo.developed_state(prm, parts, jitter=0.05, seed=12345)
+        ctx = capi.Context(prm, parts["n_fluid"], parts["n_total"], pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9, rebuild_every=64, skin_h=1.0)
+        out, prev = [], 0.0
+        worst = 0.0
+        for k in range(3000):
+            st = ctx.advance(1e9, max_steps=1)
+            d = ctx.grid_policy()["drift"] / prm.h
+            inc = d - prev if d > prev else d
+            prev = d
+            worst = max(worst, inc)
+            if k < 8 or k % 250 == 0:
+                out.append((k, round(inc, 4), round(st["vmax"], 3)))
+        print(wl, start, "worst per-step drift increment/h", round(worst, 4), out, ctx.grid_policy(), flush=True)
+        ctx.close()

@@ -1,0 +1,156 @@
+"""-m gpu: the cell grid with a skin (particles re-binned only every K-th step).
+
+Between two grid builds the sweeps are centred on the cell a particle was BINNED into; the device clock
+adds up the largest displacement per step and stops the loop before it can exceed half the skin, then
+the host re-bins ("forced rebuild") and resumes.  Whatever K and skin are, the physics must be the one
+of the reference's rebuild-every-step loop (SPH_Poiseuille.m:250-292): only the summation order may
+differ, so every schedule is compared with the oracle at the short-horizon tolerance of
+test_gpu_resident.py, and identical schedules must give identical bits.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_close, canon_pairs, make_case
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
+
+
+@pytest.fixture(scope="module")
+def case(cfgmod, geom):
+    return make_case(cfgmod, geom, dp=0.04, DL=3.0, jitter=0.3, seed=11, developed=True)
+
+
+def _ctx(capi, prm, parts, **kw):
+    return capi.Context(prm, parts["n_fluid"], parts["n_total"], parts["pos"], parts["vel"], parts["drho_dt"],
+                        parts["mass"], parts["wall_vel"], t_end=1e9, **kw)
+
+
+def _pol(ctx):
+    p = ctx.grid_policy()
+    return p["rebuild_every"], p["skin"], p["forced_rebuilds"]
+
+
+def _check(got, ref, tag):
+    for k in FIELDS:
+        assert_close(got[k], ref[k], rtol=1e-9, atol_scale=1e-10, name=f"{k}@{tag}")
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("n_steps", [4, 7])
+def test_any_rebuild_interval_matches_oracle(case, capi, oracle, K, n_steps):
+    prm, parts = case
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=n_steps, enable_sort=False)
+    with _ctx(capi, prm, parts, rebuild_every=K, lanes_per_particle=8) as ctx:
+        pol = ctx.grid_policy()
+        assert pol["rebuild_every"] == K and (pol["skin"] > 0) == (K > 1)
+        st = ctx.advance(1e9, max_steps=n_steps)
+        got = ctx.download()
+        tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
+    assert st["step"] == n_steps
+    _check(got, ref, f"K{K}")
+    assert npairs == ref["stats"]["n_pairs_last"]
+    assert_close(np.array([tb, tt]), np.array([ref["stats"]["tau_bottom"], ref["stats"]["tau_top"]]), rtol=1e-8,
+                 atol_scale=1e-9, name="tau")
+
+
+def test_undersized_skin_forces_rebuilds_and_stays_exact(case, capi, oracle):
+    """A skin far too thin for K: the device must stop the loop by itself, the host re-bins, K shrinks."""
+    prm, parts = case
+    n_steps = 12
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=n_steps, enable_sort=False)
+    with _ctx(capi, prm, parts, rebuild_every=8, skin_h=0.03, lanes_per_particle=4) as ctx:
+        st = ctx.advance(1e9, max_steps=n_steps)
+        pol = ctx.grid_policy()
+        got = ctx.download()
+        tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
+    assert st["step"] == n_steps
+    assert pol["forced_rebuilds"] >= 1 and pol["rebuild_every"] < 8
+    _check(got, ref, "forced")
+    assert npairs == ref["stats"]["n_pairs_last"]
+    assert_close(np.array([tb, tt]), np.array([ref["stats"]["tau_bottom"], ref["stats"]["tau_top"]]), rtol=1e-8,
+                 atol_scale=1e-9, name="tau")
+
+
+@pytest.mark.parametrize("kw", [dict(rebuild_every=5), dict(rebuild_every=8, skin_h=0.03), dict(rebuild_every=3, skin_h=0.05)])
+def test_call_pattern_does_not_change_the_bits(case, capi, kw):
+    """One advance, step-by-step advances and fire-and-forget batches follow the same rebuild schedule (it is
+    a function of the step count and of device-side events only) -> identical bits."""
+    prm, parts = case
+    n = 23
+    outs = []
+    with _ctx(capi, prm, parts, steps_per_graph=4, **kw) as a:
+        a.advance(1e9, max_steps=n)
+        outs.append(a.download(fields=("pos", "vel", "drho_dt", "rho", "Vol")))
+        pol_a = _pol(a)
+    with _ctx(capi, prm, parts, steps_per_graph=4, **kw) as b:
+        for _ in range(n):
+            st = b.advance(1e9, max_steps=1)
+        assert st["step"] == n
+        outs.append(b.download(fields=("pos", "vel", "drho_dt", "rho", "Vol")))
+        assert _pol(b) == pol_a
+    with _ctx(capi, prm, parts, steps_per_graph=4, **kw) as c:
+        c.enqueue_steps(9)
+        c.enqueue_steps(6)
+        st = c.sync()
+        assert st["step"] == 15
+        c.enqueue_steps(8)
+        st = c.sync()
+        assert st["step"] == n
+        outs.append(c.download(fields=("pos", "vel", "drho_dt", "rho", "Vol")))
+        assert _pol(c) == pol_a
+    for o in outs[1:]:
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], o[k]), k
+
+
+def test_interval_regrows_on_a_fixed_schedule(case, capi):
+    """After back-to-back forced rebuilds the interval shrinks; it takes a notch back every 1024 steps, at step
+    indices that do not depend on how the host chunks its calls -> still identical bits."""
+    prm, parts = case
+    kw = dict(rebuild_every=6, skin_h=0.04, steps_per_graph=8, lanes_per_particle=8)
+    n = 2300
+    with _ctx(capi, prm, parts, **kw) as a:
+        a.advance(1e9, max_steps=40)
+        early = a.grid_policy()
+        a.advance(1e9, max_steps=n - 40)
+        A = a.download(fields=("pos", "vel", "drho_dt"))
+        pol_a = _pol(a)
+    assert early["rebuild_every"] < 6 and early["forced_rebuilds"] >= 2
+    assert pol_a[2] > early["forced_rebuilds"]  # it tried the longer interval again (and was stopped again)
+    with _ctx(capi, prm, parts, **kw) as b:
+        done = 0
+        for chunk in (700, 1, 323, 1000, 276):
+            b.enqueue_steps(chunk)
+            done += chunk
+            if chunk != 1:
+                assert b.sync()["step"] == done
+        assert done == n and b.sync()["step"] == n
+        Bd = b.download(fields=("pos", "vel", "drho_dt"))
+        assert _pol(b) == pol_a
+    for k in A:
+        assert np.array_equal(A[k], Bd[k]), k
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 3, 4, 5, 6])
+def test_pair_list_between_rebuilds(case, capi, oracle, n_steps):
+    """The MEX-convention pair list taken from a stale (but still valid) grid equals a fresh search."""
+    prm, parts = case
+    with _ctx(capi, prm, parts, rebuild_every=5) as ctx:
+        ctx.advance(1e9, max_steps=n_steps)
+        nb = ctx.neighbor_list()
+        pos = ctx.download(fields=("pos",))["pos"]
+    ref = oracle.neighbor_search(pos, parts["n_fluid"], parts["n_total"], prm.h, prm.DL)
+    a, b = canon_pairs(nb), canon_pairs(ref)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert_close(a[4], b[4], rtol=1e-13, atol=1e-15 * prm.DL, name="r")
+
+
+def test_narrow_domain_falls_back_to_every_step(cfgmod, geom, capi):
+    """DL too short for three skinned cell columns -> K = 1, no skin (the periodic sweep needs ncx >= 3)."""
+    prm, parts = make_case(cfgmod, geom, dp=0.05, DL=0.45, jitter=0.1, seed=3, developed=True)
+    with _ctx(capi, prm, parts, rebuild_every=6, skin_h=0.5) as ctx:
+        pol = ctx.grid_policy()
+        assert pol["rebuild_every"] == 1 and pol["skin"] == 0.0
+        assert ctx.advance(1e9, max_steps=3)["step"] == 3
