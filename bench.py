@@ -36,9 +36,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_FLUID = {"k_density": 40, "k_kgc": 56, "k_forces": 112 + 192, "k_continuity": 104,
                    "k_clock_scan": 0, "k_scatter": 8, "k_reorder": 16}
 BYTES_PER_WALL = {"k_density": 24, "k_kgc": 24, "k_forces": 48, "k_continuity": 24}
-for _k in ("k_density", "k_kgc", "k_forces", "k_continuity"):  # LDS-tiled variants: same algorithmic bytes
-    BYTES_PER_FLUID[_k + "_t"] = BYTES_PER_FLUID[_k]
-    BYTES_PER_WALL[_k + "_t"] = BYTES_PER_WALL[_k]
 STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
 
 
@@ -91,7 +88,7 @@ def pmc_traffic(name, kernel):
         return None
 
 
-def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=0, tile=0, lattice=False,
+def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=0, lattice=False,
              rebuild_every=0, skin_h=0.0):
     """Time `steps` resident steps of one workload; returns (result dict, prm, parts, pos, vel)."""
     import torch
@@ -104,7 +101,7 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
         pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
         start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
     ctx = capi.Context(prm, nf, nt, pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9,
-                       lanes_per_particle=lpp, steps_per_graph=spg, tile_cells=tile, rebuild_every=rebuild_every,
+                       lanes_per_particle=lpp, steps_per_graph=spg, rebuild_every=rebuild_every,
                        skin_h=skin_h)
     info, tuning = ctx.info(), ctx.tuning()
     if warmup > 0:
@@ -156,7 +153,6 @@ def main():
     ap.add_argument("--workload", default=None, help="C1..C5 or 'dp=0.01,DL=6' (default: C2 at 1 GPU)")
     ap.add_argument("--lpp", type=int, default=0, help="lanes per particle (0 = auto)")
     ap.add_argument("--spg", type=int, default=0, help="steps per hipGraph replay (0 = auto)")
-    ap.add_argument("--tile", type=int, default=0, help="cells per LDS tile (0 = auto, -1 = list-walking kernels only)")
     ap.add_argument("--rebuild-every", type=int, default=0, help="re-bin particles every K-th step (0 = auto)")
     ap.add_argument("--skin", type=float, default=0.0, help="cell skin in units of h (0 = sized from K)")
     ap.add_argument("--profile-steps", type=int, default=200, help="eager steps timed per kernel with HIP events")
@@ -189,7 +185,7 @@ def main():
 
     name, kw = parse_workload(args.workload or "C2")
     r, prm, parts, pos, vel = run_case(capi, cfg, geo, name, kw, args.steps, args.warmup, args.profile_steps, args.lpp,
-                                       args.spg, args.tile, args.lattice, args.rebuild_every, args.skin)
+                                       args.spg, args.lattice, args.rebuild_every, args.skin)
     value = r["value"]
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,

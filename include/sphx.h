@@ -144,8 +144,7 @@ typedef struct sphx_params {
     int32_t sort_interval;  /* kept for signature parity; the device re-sorts by cell every step     */
     int32_t lanes_per_particle; /* 0 = auto; 1,2,4,8,16,32: lanes cooperating on one neighbour ring */
     int32_t steps_per_graph;    /* 0 = auto; steps captured per hipGraph replay (even)               */
-    int32_t reserved;           /* tile_cells: >0 = experimental LDS-tiled neighbour passes with that many
-                                   cells per tile; <=0 = list-walking passes (default)                 */
+    int32_t reserved;           /* must be 0                                                         */
     int32_t rebuild_every;      /* 0 = auto; K >= 1: particles are re-binned into cells every K-th step; in
                                    between, sweeps are centred on the cell a particle was binned into and
                                    the cells carry a skin (results do not depend on K beyond summation

@@ -57,18 +57,25 @@ struct Clock {
     int pad;
 };
 
+// Everything a neighbour pass GATHERS per neighbour is stored as 16- or 32-byte records (position, velocity,
+// {Vol, p_half, rho_half, rho}, B): the passes are bound by the number of scattered load instructions (texture
+// addresser), not by bytes, and one 16-byte load costs the same address work as one 8-byte load.
 struct FluidSet {  // persistent per-particle state, sorted by cell
-    double *x, *y, *vx, *vy, *drho, *mass;
+    double2 *pos, *vel;
+    double *drho, *mass;
     int *id;
     int *start;  // [ncells+1] cell ranges of this ordering
     int *cell;   // [n] the cell each slot was BINNED into (positions may since have drifted by < skin/2)
-    double *xb, *yb;  // [n] position at binning time (nullptr: grid rebuilt every step, drift not tracked)
+    double2 *posb;  // [n] position at binning time (nullptr: grid rebuilt every step, drift not tracked)
 };
 
 struct FluidTmp {
-    double *xn, *yn, *vxn, *vyn, *drhon;                   // end-of-step state, pre-sort order
-    double *rho, *Vol, *rhoh, *ph, *b11, *b12, *b21, *b22;  // per-step fields
-    double *fpx, *fpy, *fx, *fy, *rho_out, *p_out;         // outputs of the step
+    double2 *posn, *veln;      // end-of-step state, pre-sort order
+    double *drhon;
+    double4 *a;                // per-step fields {Vol, p_half, rho_half, rho}
+    double4 *B;                // per-step KGC matrix {B11, B12, B21, B22}
+    double2 *fp, *f;           // outputs of the step: force_prior, force
+    double *rho_out, *p_out;
     int *cellid, *count, *perm, *src_of;
     double *vpart;   // per-block max |v|^2 of pass E (owned particles only)
     double *dpart;   // per-block max drift^2 from the binning positions after this step (pass CD)
@@ -80,7 +87,8 @@ struct FluidTmp {
 };
 
 struct Walls {
-    const double *x, *y, *Vol, *vx, *vy;
+    const double2 *pos;
+    const double4 *a;  // {Vol, vx, vy, 0}
     const int *id;
     const int *start;    // [ncells+1]
     const int *row_any;  // [ncy] 1 when rows cy-1..cy+1 hold any wall particle
@@ -208,7 +216,8 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     // lane then owns ceil-or-floor(cnt / LPP) neighbours in the later passes (balanced trip counts) and the lanes
     // of a group walk adjacent particles, so a gather touches a few cache lines instead of ~27.
     if (active) {
-        const double xi = s.x[i], yi = s.y[i];
+        const double2 pi = s.pos[i];
+        const double xi = pi.x, yi = pi.y;
         int cx, cy;
         binned_cell(g, s, i, cx, cy);
         const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
@@ -228,7 +237,8 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                 const int k = kb + sub;
                 bool acc = false;
                 if (k < hi) {
-                    const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+                    const double2 pj = s.pos[k];
+                    const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                         acc = true;
@@ -253,9 +263,10 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
         }
         if (w.row_any[cy]) {
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double2 pj = w.pos[k];
+                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                 const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * w.Vol[k];
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * w.a[k].x;
             });
         }
         if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
@@ -271,10 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
         const double dt = clk->dt;
         double rhoh = rho + 0.5 * dt * s.drho[i];
         if (rhoh < 1e-10) rhoh = ph.rho0;
-        t.rho[i] = rho;
-        t.Vol[i] = m / rho;
-        t.rhoh[i] = rhoh;
-        t.ph[i] = eos_pressure(rhoh, ph.rho0, ph.p0);
+        t.a[i] = make_double4(m / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho);
     }
 }
 
@@ -294,7 +302,8 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
     const bool active = i < n;
     double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
     if (active) {
-        const double xi = s.x[i], yi = s.y[i];
+        const double2 pi = s.pos[i];
+        const double xi = pi.x, yi = pi.y;
         auto term = [&](double dx, double dy, double Volj) {
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
@@ -307,15 +316,17 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
         const int nn = t.nl_cnt[tid];
         for (int m = 0; m < nn; ++m) {
             const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
-            term(min_image(g, xi - s.x[k]), yi - s.y[k], t.Vol[k]);
+            const double2 pj = s.pos[k];
+            term(min_image(g, xi - pj.x), yi - pj.y, t.a[k].x);
         }
         int cx, cy;
         binned_cell(g, s, i, cx, cy);
         if (w.row_any[cy]) {
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double2 pj = w.pos[k];
+                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                 const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) term(dx, dy, w.Vol[k]);
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) term(dx, dy, w.a[k].x);
             });
         }
     }
@@ -325,10 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
     a22 = group_sum<LPP>(a22);
     if (active && sub == 0) {
         const Mat2 B = kgc_from_A(a11, a12, a21, a22);
-        t.b11[i] = B.m11;
-        t.b12[i] = B.m12;
-        t.b21[i] = B.m21;
-        t.b22[i] = B.m22;
+        t.B[i] = make_double4(B.m11, B.m12, B.m21, B.m22);
     }
 }
 
@@ -357,21 +365,25 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     int cx = 0, cy = 0;
     bool near_wall = false;
     if (active) {
-        xi = s.x[i]; yi = s.y[i]; vxi = s.vx[i]; vyi = s.vy[i];
-        Voli = t.Vol[i]; mi = s.mass[i]; p_i = t.ph[i]; rhoh_i = t.rhoh[i];
-        b11i = t.b11[i]; b12i = t.b12[i]; b21i = t.b21[i]; b22i = t.b22[i];
+        const double2 pi = s.pos[i], vi = s.vel[i];
+        const double4 ai = t.a[i], Bi = t.B[i];
+        xi = pi.x; yi = pi.y; vxi = vi.x; vyi = vi.y;
+        Voli = ai.x; mi = s.mass[i]; p_i = ai.y; rhoh_i = ai.z;
+        b11i = Bi.x; b12i = Bi.y; b21i = Bi.z; b22i = Bi.w;
         const int nn = t.nl_cnt[tid];
         for (int m = 0; m < nn; ++m) {
             const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
-            const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+            const double2 pj = s.pos[k], vj = s.vel[k];
+            const double4 aj = t.a[k], Bj = t.B[k];
+            const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
             const double dW = spline_dW(ph.kc, r);
-            const double Volj = t.Vol[k];
-            const double tx = (b11i + t.b11[k]) * ex + (b12i + t.b12[k]) * ey;
-            const double ty = (b21i + t.b21[k]) * ex + (b22i + t.b22[k]) * ey;
+            const double Volj = aj.x;
+            const double tx = (b11i + Bj.x) * ex + (b12i + Bj.y) * ey;
+            const double ty = (b21i + Bj.z) * ex + (b22i + Bj.w) * ey;
             const double eBe = ex * tx + ey * ty;
-            const double vxj = s.vx[k], vyj = s.vy[k];
+            const double vxj = vj.x, vyj = vj.y;
             const double dWVj = dW * Volj;
             // viscous
             const double coeff = eBe * ph.mu * dWVj / (r + 0.01 * h);
@@ -381,8 +393,8 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
             ix -= dWVj * tx;
             iy -= dWVj * ty;
             // pressure (Riemann-dissipated face pressure)
-            const double p_j = t.ph[k];
-            const double rho_bar = 0.5 * (rhoh_i + t.rhoh[k]);
+            const double p_j = aj.y;
+            const double rho_bar = 0.5 * (rhoh_i + aj.z);
             const double un_l = vxi * ex + vyi * ey, un_r = vxj * ex + vyj * ey;
             const double beta = riemann_beta(un_l, un_r, ph.c_f);
             const double p_avg = 0.5 * (p_i + p_j);
@@ -395,17 +407,19 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         near_wall = w.row_any[cy] != 0;
         if (near_wall) {
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double2 pj = w.pos[k];
+                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                 const double r2 = dx * dx + dy * dy;
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                    const double4 wj = w.a[k];
                     const double inv_r = rsqrt(r2), r = r2 * inv_r;
                     const double ex = dx * inv_r, ey = dy * inv_r;
-                    const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
+                    const double dWVj = spline_dW(ph.kc, r) * wj.x;
                     const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
                     const double eBe = ex * tx + ey * ty;
                     const double coeff = 4.0 * eBe * ph.mu * dWVj / (r + 0.01 * h);
-                    ax += coeff * (vxi - w.vx[k]);
-                    ay += coeff * (vyi - w.vy[k]);
+                    ax += coeff * (vxi - wj.y);
+                    ay += coeff * (vyi - wj.z);
                     ix -= 2.0 * dWVj * tx;
                     iy -= 2.0 * dWVj * ty;
                 }
@@ -421,12 +435,13 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     if (active && near_wall) {
         const double acx = fpx / mi, acy = fpy / mi;
         sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-            const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+            const double2 pj = w.pos[k];
+            const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy;
             if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                 const double inv_r = rsqrt(r2), r = r2 * inv_r;
                 const double ex = dx * inv_r, ey = dy * inv_r;
-                const double dWVj = spline_dW(ph.kc, r) * w.Vol[k];
+                const double dWVj = spline_dW(ph.kc, r) * w.a[k].x;
                 const double face = -(acx * ex + acy * ey);
                 const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
                 const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
@@ -450,19 +465,16 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         yo += 0.5 * dt * vyi;
         xo += 0.5 * dt * vxn;
         yo += 0.5 * dt * vyn;
-        if (s.xb) {
-            const double ddx = min_image(g, xo - s.xb[i]), ddy = yo - s.yb[i];
+        if (s.posb) {
+            const double2 pb = s.posb[i];
+            const double ddx = min_image(g, xo - pb.x), ddy = yo - pb.y;
             d2 = ddx * ddx + ddy * ddy;
             if (d2 != d2) d2 = INFINITY;
         }
-        t.xn[i] = g.periodic ? wrap_x(xo, ph.DL) : xo;  // a slab wraps when particles change owner
-        t.yn[i] = yo;
-        t.vxn[i] = vxn;
-        t.vyn[i] = vyn;
-        t.fpx[i] = fpx;
-        t.fpy[i] = fpy;
-        t.fx[i] = fx;
-        t.fy[i] = fy;
+        t.posn[i] = make_double2(g.periodic ? wrap_x(xo, ph.DL) : xo, yo);  // a slab wraps when particles change owner
+        t.veln[i] = make_double2(vxn, vyn);
+        t.fp[i] = make_double2(fpx, fpy);
+        t.f[i] = make_double2(fx, fy);
     }
     // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
 #pragma unroll
@@ -553,31 +565,35 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     double rate = 0.0, v2 = 0.0;
     double vxi = 0.0, vyi = 0.0, xi = 0.0;
     if (active) {
-        xi = s.x[i];
-        const double yi = s.y[i];
-        vxi = t.vxn[i];
-        vyi = t.vyn[i];
+        const double2 pi = s.pos[i], vi = t.veln[i];
+        xi = pi.x;
+        const double yi = pi.y;
+        vxi = vi.x;
+        vyi = vi.y;
         const int nn = t.nl_cnt[tid];
         for (int m = 0; m < nn; ++m) {
             const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
-            const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+            const double2 pj = s.pos[k], vj = t.veln[k];
+            const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
-            const double u_jump = (vxi - t.vxn[k]) * ex + (vyi - t.vyn[k]) * ey;
-            rate += u_jump * spline_dW(ph.kc, r) * t.Vol[k];
+            const double u_jump = (vxi - vj.x) * ex + (vyi - vj.y) * ey;
+            rate += u_jump * spline_dW(ph.kc, r) * t.a[k].x;
         }
         int cx, cy;
         binned_cell(g, s, i, cx, cy);
         if (w.row_any[cy]) {
             sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double2 pj = w.pos[k];
+                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                 const double r2 = dx * dx + dy * dy;
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                    const double4 wj = w.a[k];
                     const double inv_r = rsqrt(r2), r = r2 * inv_r;
                     const double ex = dx * inv_r, ey = dy * inv_r;
-                    const double vjx = 2.0 * w.vx[k] - vxi, vjy = 2.0 * w.vy[k] - vyi;
+                    const double vjx = 2.0 * wj.y - vxi, vjy = 2.0 * wj.z - vyi;
                     const double jump = (vxi - vjx) * ex + (vyi - vjy) * ey;
-                    rate += jump * spline_dW(ph.kc, r) * w.Vol[k];
+                    rate += jump * spline_dW(ph.kc, r) * wj.x;
                 }
             });
         }
@@ -585,7 +601,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     rate = group_sum<LPP>(rate);
     if (active && sub == 0) {
         const double dt = clk->dt;
-        const double rhoh = t.rhoh[i];
+        const double rhoh = t.a[i].z;
         const double drho_new = rate * rhoh;
         double rho = rhoh + drho_new * (0.5 * dt);
         if (rho < 1e-10) rho = ph.rho0;
@@ -598,7 +614,8 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
         }
         if (do_hist) {
             int cx, cy;
-            cell_of(g, t.xn[i], t.yn[i], cx, cy);
+            const double2 pn = t.posn[i];
+            cell_of(g, pn.x, pn.y, cx, cy);
             const int c = cx * g.ncy + cy;
             t.cellid[i] = c;
             atomicAdd(&t.count[c], 1);
@@ -617,15 +634,16 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
 }
 
 // standalone cell histogram (context creation, wall grid, slab steps): same binning as pass E
-__global__ __launch_bounds__(kBlock) void k_bin(const Clock *clk, int q, Grid g, int n_fixed, const double *x,
-                                                const double *y, int *cellid, int *count)
+__global__ __launch_bounds__(kBlock) void k_bin(const Clock *clk, int q, Grid g, int n_fixed, const double2 *pos,
+                                                int *cellid, int *count)
 {
     if (clk && !clk->run[q]) return;
     const int n = clk ? clk->n : n_fixed;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     int cx, cy;
-    cell_of(g, x[i], y[i], cx, cy);
+    const double2 p = pos[i];
+    cell_of(g, p.x, p.y, cx, cy);
     const int c = cx * g.ncy + cy;
     cellid[i] = c;
     atomicAdd(&count[c], 1);
@@ -772,9 +790,13 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int
 }
 
 struct ReorderArgs {
-    int nd;
-    const double *src[8];
-    double *dst[8];
+    int n1, n2, n4;  // number of 8-, 16- and 32-byte fields
+    const double *src1[2];
+    double *dst1[2];
+    const double2 *src2[3];
+    double2 *dst2[3];
+    const double4 *src4[1];
+    double4 *dst4[1];
     const int *id_src;
     int *id_dst;
     int *src_of;
@@ -802,8 +824,12 @@ __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int
     }
     const int dst = lo + rank;
 #pragma unroll
-    for (int f = 0; f < 8; ++f)
-        if (f < a.nd) a.dst[f][dst] = a.src[f][i];
+    for (int f = 0; f < 3; ++f)
+        if (f < a.n2) a.dst2[f][dst] = a.src2[f][i];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+        if (f < a.n1) a.dst1[f][dst] = a.src1[f][i];
+    if (a.n4) a.dst4[0][dst] = a.src4[0][i];
     a.id_dst[dst] = my_id;
     if (a.src_of) a.src_of[dst] = i;
     if (a.cell_dst) a.cell_dst[dst] = c;
@@ -821,16 +847,10 @@ __global__ __launch_bounds__(kBlock) void k_iota(int n, int *a, int base)
     if (i < n) a[i] = base + i;
 }
 
-__global__ __launch_bounds__(kBlock) void k_wrap_x(int n, double *x, double DL)
+__global__ __launch_bounds__(kBlock) void k_wrap_x(int n, double2 *pos, double DL)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) x[i] = wrap_x(x[i], DL);
-}
-
-__global__ __launch_bounds__(kBlock) void k_wall_volume(int n, const double *mass, double rho0, double *Vol)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) Vol[i] = mass[i] / rho0;  // walls keep rho = rho0 (sph_physics_mex.c:214-216,233)
+    if (i < n) pos[i].x = wrap_x(pos[i].x, DL);
 }
 
 __global__ void k_row_any(Grid g, const int *wstart, int *row_any)
@@ -847,14 +867,16 @@ __global__ void k_row_any(Grid g, const int *wstart, int *row_any)
 }
 
 // initial max |v| over owned particles (vecnorm over the fluid, SPH_Poiseuille.m:521); single block
-__global__ __launch_bounds__(kScanBlock) void k_vmax_init(Clock *clk, Grid g, const double *x, const double *vx,
-                                                          const double *vy, double *vmax_out)
+__global__ __launch_bounds__(kScanBlock) void k_vmax_init(Clock *clk, Grid g, const double2 *pos, const double2 *vel,
+                                                          double *vmax_out)
 {
     const int n = clk->n;
     double m = 0.0;
     for (int k = threadIdx.x; k < n; k += kScanBlock) {
-        if (!(x[k] >= g.own_lo && x[k] < g.own_hi)) continue;
-        double v2 = vx[k] * vx[k] + vy[k] * vy[k];
+        const double x = pos[k].x;
+        if (!(x >= g.own_lo && x < g.own_hi)) continue;
+        const double2 v = vel[k];
+        double v2 = v.x * v.x + v.y * v.y;
         if (v2 != v2) v2 = INFINITY;
         m = fmax(m, v2);
     }
@@ -883,24 +905,27 @@ __global__ __launch_bounds__(kBlock) void k_wall_shear(const Clock *clk, Grid g,
     const int i = blockIdx.x * kBlock + threadIdx.x;
     double fb = 0.0, ft = 0.0;
     if (i < n) {
-        const double xi = s.x[i], yi = s.y[i];
+        const double xi = s.pos[i].x, yi = s.pos[i].y;
         int cx, cy;
         binned_cell(g, s, i, cx, cy);
         if (w.row_any[cy] && xi >= g.own_lo && xi < g.own_hi) {
             const int o = use_src ? t.src_of[i] : i;
-            const double Voli = t.Vol[o];
-            const double b11 = t.b11[o], b12 = t.b12[o], b21 = t.b21[o], b22 = t.b22[o];
-            const double vxi = s.vx[i];
+            const double Voli = t.a[o].x;
+            const double4 Bo = t.B[o];
+            const double b11 = Bo.x, b12 = Bo.y, b21 = Bo.z, b22 = Bo.w;
+            const double vxi = s.vel[i].x;
             sweep<1>(g, w.start, cx, cy, 0, [&](int k) {
-                const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+                const double2 pj = w.pos[k];
+                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                 const double r2 = dx * dx + dy * dy;
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                    const double4 wj = w.a[k];
                     const double r = sqrt(r2);
                     const double ex = dx / r, ey = dy / r;
                     const double eBe = ex * (b11 * ex + b12 * ey) + ey * (b21 * ex + b22 * ey);
-                    const double f = 4.0 * ph.mu * eBe * spline_dW(ph.kc, r) * w.Vol[k] * (vxi - w.vx[k]) /
+                    const double f = 4.0 * ph.mu * eBe * spline_dW(ph.kc, r) * wj.x * (vxi - wj.y) /
                                      (r + 0.01 * ph.kc.h) * Voli;
-                    const double yj = w.y[k];
+                    const double yj = pj.y;
                     if (yj <= 0.0) fb += f;
                     else if (yj >= ph.DH) ft += f;
                 }
@@ -951,7 +976,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(const Clock *clk, Grid g, Phys
     const int nf = clk->n;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nf) return;
-    const double xi = s.x[i], yi = s.y[i];
+    const double xi = s.pos[i].x, yi = s.pos[i].y;
     const int a = s.id[i];
     int cx, cy;
     binned_cell(g, s, i, cx, cy);
@@ -970,7 +995,8 @@ __global__ __launch_bounds__(kBlock) void k_pairs(const Clock *clk, Grid g, Phys
         ++n;
     };
     sweep<1>(g, s.start, cx, cy, 0, [&](int k) {
-        const double dx = min_image(g, xi - s.x[k]), dy = yi - s.y[k];
+        const double2 pj = s.pos[k];
+        const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
         const double r2 = dx * dx + dy * dy;
         if (r2 > kR2Min && r2 < ph.kc.rcut2) {
             const int b = s.id[k];
@@ -979,7 +1005,8 @@ __global__ __launch_bounds__(kBlock) void k_pairs(const Clock *clk, Grid g, Phys
     });
     if (w.row_any[cy]) {
         sweep<1>(g, w.start, cx, cy, 0, [&](int k) {
-            const double dx = min_image(g, xi - w.x[k]), dy = yi - w.y[k];
+            const double2 pj = w.pos[k];
+            const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy;
             if (r2 > kR2Min && r2 < ph.kc.rcut2) emit(w.id[k], dx, dy, r2);
         });
@@ -987,11 +1014,11 @@ __global__ __launch_bounds__(kBlock) void k_pairs(const Clock *clk, Grid g, Phys
     if (!MODE) cnt[a] = n;
 }
 
-// scatter a sorted field back to the caller's row numbering
-__global__ __launch_bounds__(kBlock) void k_unsort(int n, const int *id, const double *src, double *dst)
+// scatter one component of a sorted field (records of `stride` doubles) back to the caller's row numbering
+__global__ __launch_bounds__(kBlock) void k_unsort(int n, const int *id, const double *src, int stride, double *dst)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) dst[id[i]] = src[i];
+    if (i < n) dst[id[i]] = src[(size_t)i * stride];
 }
 
 __global__ __launch_bounds__(kBlock) void k_fill(int n, double *dst, double v)
@@ -1013,7 +1040,8 @@ __global__ __launch_bounds__(kBlock) void k_fill(int n, double *dst, double v)
 struct SlabPack {
     double *send_l, *send_r;   // device message buffers
     int *counters;             // [3]: keep, left, right (zeroed by k_slab_unpack of the previous step)
-    double *kx, *ky, *kvx, *kvy, *kdrho, *kmass;  // keep arrays (compacted)
+    double2 *kpos, *kvel;      // keep arrays (compacted)
+    double *kdrho, *kmass;
     int *kid;
     double halo_w, shift_l, shift_r, win_lo, win_hi;
     int msg_cap, keep_cap;
@@ -1039,14 +1067,15 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(const Clock *clk, int q, G
     const int n = clk->n;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const double x_ref = s.x[i];
+    const double x_ref = s.pos[i].x;
     if (!(x_ref >= g.own_lo && x_ref < g.own_hi)) return;  // halo copy
-    const double xn = t.xn[i], yn = t.yn[i], vxn = t.vxn[i], vyn = t.vyn[i], dr = t.drhon[i], m = s.mass[i];
+    const double2 pn = t.posn[i], vn = t.veln[i];
+    const double xn = pn.x, yn = pn.y, vxn = vn.x, vyn = vn.y, dr = t.drhon[i], m = s.mass[i];
     const int id = s.id[i];
     if (xn >= p.win_lo && xn < p.win_hi) {
         const int k = atomicAdd(&p.counters[0], 1);
         if (k < p.keep_cap) {
-            p.kx[k] = xn; p.ky[k] = yn; p.kvx[k] = vxn; p.kvy[k] = vyn; p.kdrho[k] = dr; p.kmass[k] = m; p.kid[k] = id;
+            p.kpos[k] = pn; p.kvel[k] = vn; p.kdrho[k] = dr; p.kmass[k] = m; p.kid[k] = id;
         } else atomicOr(t.flags, 2);
     }
     if (xn < g.own_lo + p.halo_w) {
@@ -1087,10 +1116,8 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const Clock *clk, int q,
         const double *b = (i < nl ? recv_l : recv_r) + 1;
         const int sl = i < nl ? i : i - nl;
         const int d = nk + i;
-        p.kx[d] = b[sl];
-        p.ky[d] = b[(size_t)cap + sl];
-        p.kvx[d] = b[2 * (size_t)cap + sl];
-        p.kvy[d] = b[3 * (size_t)cap + sl];
+        p.kpos[d] = make_double2(b[sl], b[(size_t)cap + sl]);
+        p.kvel[d] = make_double2(b[2 * (size_t)cap + sl], b[3 * (size_t)cap + sl]);
         p.kdrho[d] = b[4 * (size_t)cap + sl];
         p.kmass[d] = b[5 * (size_t)cap + sl];
         p.kid[d] = (int)b[6 * (size_t)cap + sl];

@@ -9,7 +9,6 @@
 
 #include "sphx_common.hpp"
 #include "sphx_kernels.hpp"
-#include "sphx_kernels_tiled.hpp"
 
 namespace sphx {
 
@@ -62,10 +61,7 @@ struct sphx_ctx {
     int cap = 0;                 // particle capacity of the device arrays
     int lpp = 1, spg = 2;
     bool big_scan = false;
-    bool tiled = false;          // LDS-tiled neighbour passes (experimental)
-    TileCfg tcfg{};
     int n_vpart = 0;             // entries of vpart / dpart the clock kernel reduces
-    DevBuf<unsigned short> nl16;
     int n_tiles = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
@@ -94,11 +90,15 @@ struct sphx_ctx {
     bool have_step_outputs = false;
 
     // storage
-    DevBuf<double> fx_[2], fy_[2], fvx_[2], fvy_[2], fdrho_[2], fmass_[2], fxb_[2], fyb_[2];
+    DevBuf<double2> fpos_[2], fvel_[2], fposb_[2];
+    DevBuf<double> fdrho_[2], fmass_[2];
     DevBuf<int> fid_[2], fstart_[2], fcell_[2];
-    DevBuf<double> xn, yn, vxn, vyn, drhon, rho, Vol, rhoh, ph, b11, b12, b21, b22, fpx, fpy, ffx, ffy, rho_out, p_out, vpart, dpart;
+    DevBuf<double2> posn, veln, ffp, ff;
+    DevBuf<double4> fa, fB;
+    DevBuf<double> drhon, rho_out, p_out, vpart, dpart;
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, flags, tile;
-    DevBuf<double> wx, wy, wVol, wvx, wvy;
+    DevBuf<double2> wpos;
+    DevBuf<double4> wa;
     DevBuf<int> wid, wstart, wrow_any;
     DevBuf<Clock> clock;
     DevBuf<double> tau_part, tau_out;
@@ -123,7 +123,8 @@ struct sphx_ctx {
     bool is_slab = false;
     int rank = 0, n_ranks = 1, halo_cols = 0, msg_cap = 0;
     int col0 = 0, col1 = 0;  // owned global columns [col0, col1)
-    DevBuf<double> kx, ky, kvx, kvy, kdrho, kmass;
+    DevBuf<double2> kpos, kvel;
+    DevBuf<double> kdrho, kmass;
     DevBuf<int> kid, counters, n_new;
     SlabPack pack{};
     int64_t slab_steps_enqueued = 0, slab_step0 = 0;
@@ -134,9 +135,8 @@ struct sphx_ctx {
 
     FluidSet view(int q, int l)
     {
-        return FluidSet{fx_[q].get(), fy_[q].get(), fvx_[q].get(), fvy_[q].get(), fdrho_[q].get(), fmass_[l].get(),
-                        fid_[l].get(), fstart_[l].get(), fcell_[l].get(), skin > 0.0 ? fxb_[l].get() : nullptr,
-                        skin > 0.0 ? fyb_[l].get() : nullptr};
+        return FluidSet{fpos_[q].get(), fvel_[q].get(), fdrho_[q].get(), fmass_[l].get(), fid_[l].get(),
+                        fstart_[l].get(), fcell_[l].get(), skin > 0.0 ? fposb_[l].get() : nullptr};
     }
     double half_skin() const { return 0.5 * skin; }
 
@@ -187,17 +187,21 @@ void launch(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, Args
     launch_s(c, name, kernel, grid, block, 0, args...);
 }
 
-ReorderArgs reorder_args(const double *const src[6], const int *id_src, const FluidSet &d, int *src_of)
+// gather of the persistent fields (pos, vel, drho, mass) into destination view d
+ReorderArgs reorder_args(const double2 *pos, const double2 *vel, const double *drho, const double *mass, const int *id_src,
+                         const FluidSet &d, int *src_of)
 {
     ReorderArgs ra{};
-    ra.nd = 6;
-    double *dst[6] = {d.x, d.y, d.vx, d.vy, d.drho, d.mass};
-    for (int f = 0; f < 6; ++f) { ra.src[f] = src[f]; ra.dst[f] = dst[f]; }
-    if (d.xb) {  // remember where every particle was when it was binned
-        ra.nd = 8;
-        ra.src[6] = src[0]; ra.dst[6] = d.xb;
-        ra.src[7] = src[1]; ra.dst[7] = d.yb;
+    ra.n2 = 2;
+    ra.src2[0] = pos; ra.dst2[0] = d.pos;
+    ra.src2[1] = vel; ra.dst2[1] = d.vel;
+    if (d.posb) {  // remember where every particle was when it was binned
+        ra.n2 = 3;
+        ra.src2[2] = pos; ra.dst2[2] = d.posb;
     }
+    ra.n1 = 2;
+    ra.src1[0] = drho; ra.dst1[0] = d.drho;
+    ra.src1[1] = mass; ra.dst1[1] = d.mass;
     ra.id_src = id_src;
     ra.id_dst = d.id;
     ra.src_of = src_of;
@@ -212,25 +216,6 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
-    if (c->tiled) {
-        const TileCfg tc = c->tcfg;
-        const dim3 gt(c->grid.ncx * tc.nseg);
-        const size_t H = (size_t)tc.hcap * sizeof(double);
-        unsigned short *nl = c->nl16.get();
-        if (!only || only == 1)
-            launch_s(c, "k_density_t", k_density_t<LPP>, gt, bp, 2 * H + 3 * (size_t)(tc.ct + 4) * sizeof(int), clk, q,
-                     c->grid, c->phys, s, t, c->walls, tc, nl);
-        if (!only || only == 2)
-            launch_s(c, "k_kgc_t", k_kgc_t<LPP>, gt, bp, 3 * H, clk, q, c->grid, c->phys, s, t, c->walls, tc,
-                     (const unsigned short *)nl);
-        if (!only || only == 3)
-            launch_s(c, "k_forces_t", k_forces_t<LPP>, gt, bp, 11 * H, clk, q, c->grid, c->phys, s, t, c->walls, tc,
-                     (const unsigned short *)nl);
-        if (!only || only == 4)
-            launch_s(c, "k_continuity_t", k_continuity_t<LPP>, gt, bp, 5 * H, clk, q, c->grid, c->phys, s, t, c->walls,
-                     do_hist, tc, (const unsigned short *)nl);
-        return;
-    }
     if (!only || only == 1) launch(c, "k_density", k_density<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
     if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
     if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
@@ -267,14 +252,13 @@ void launch_cell_scan(sphx_ctx *c, const Clock *clk, int q, int *start_next)
 }
 
 // index -> cell slot, then the gather of the persistent fields into destination view d
-void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const double *const src[6], const int *id_src,
-                            const FluidSet &d, int *src_of)
+void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderArgs &ra, const FluidSet &d)
 {
     const dim3 g1(c->n_blocks_flat), bp(kBlock);
     launch(c, "k_scatter", k_scatter, g1, bp, clk, q, 0, (const int *)c->cellid.get(), c->count.get(), (const int *)d.start,
            c->perm.get());
     launch(c, "k_reorder", k_reorder, g1, bp, clk, q, 0, (const int *)c->cellid.get(), (const int *)d.start,
-           (const int *)c->perm.get(), reorder_args(src, id_src, d, src_of));
+           (const int *)c->perm.get(), ra);
 }
 
 // One single-GPU step slot: state S[q], layout L[l].  rebuild: the step ends with re-binning into S[1-q], L[1-l]
@@ -288,7 +272,7 @@ void launch_step(sphx_ctx *c, int q, int l, bool rebuild)
     if (!rebuild) {
         FluidTmp t = c->tmp;
         const FluidSet o = c->view(1 - q, l);
-        t.xn = o.x; t.yn = o.y; t.vxn = o.vx; t.vyn = o.vy; t.drhon = o.drho;
+        t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
         launch_physics_any(c, q, s, t, 0);
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(), (const int *)nullptr,
@@ -297,7 +281,6 @@ void launch_step(sphx_ctx *c, int q, int l, bool rebuild)
     }
     launch_physics_any(c, q, s, c->tmp, 1);
     const FluidSet d = c->view(1 - q, 1 - l);
-    const double *src[6] = {c->tmp.xn, c->tmp.yn, c->tmp.vxn, c->tmp.vyn, c->tmp.drhon, s.mass};
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(),
@@ -312,7 +295,7 @@ void launch_step(sphx_ctx *c, int q, int l, bool rebuild)
         launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                (const int *)tile_off, c->grid.ncells, c->n_tiles);
     }
-    launch_scatter_reorder(c, clk, q, src, s.id, d, c->tmp.src_of);
+    launch_scatter_reorder(c, clk, q, reorder_args(c->tmp.posn, c->tmp.veln, c->tmp.drhon, s.mass, s.id, d, c->tmp.src_of), d);
 }
 
 constexpr int64_t kRegrowSteps = 1024;
@@ -445,15 +428,15 @@ void forced_rebuild(sphx_ctx *c)
     const dim3 g1(c->n_blocks_flat), bp(kBlock);
     const bool prof = c->profiling;
     c->profiling = false;
-    hipLaunchKernelGGL(k_bin, g1, bp, 0, st, (const Clock *)nullptr, 0, c->grid, n, (const double *)s.x, (const double *)s.y,
-                       c->cellid.get(), c->count.get());
+    hipLaunchKernelGGL(k_bin, g1, bp, 0, st, (const Clock *)nullptr, 0, c->grid, n, (const double2 *)s.pos, c->cellid.get(),
+                       c->count.get());
     launch_cell_scan(c, nullptr, 0, d.start);
-    const double *src[6] = {s.x, s.y, s.vx, s.vy, s.drho, s.mass};
     hipLaunchKernelGGL(k_scatter, g1, bp, 0, st, (const Clock *)nullptr, 0, n, (const int *)c->cellid.get(), c->count.get(),
                        (const int *)d.start, c->perm.get());
     // src_of: new slot -> slot of the layout the last step's outputs (rho, p, force, Vol, B) are stored in
     hipLaunchKernelGGL(k_reorder, g1, bp, 0, st, (const Clock *)nullptr, 0, n, (const int *)c->cellid.get(),
-                       (const int *)d.start, (const int *)c->perm.get(), reorder_args(src, s.id, d, c->tmp.src_of));
+                       (const int *)d.start, (const int *)c->perm.get(),
+                       reorder_args(s.pos, s.vel, s.drho, s.mass, s.id, d, c->tmp.src_of));
     hipLaunchKernelGGL(k_rebinned, dim3(1), dim3(1), 0, st, c->clock.get());
     c->profiling = prof;
     SPHX_HIP(hipGetLastError());
@@ -500,15 +483,15 @@ int pick_lpp(int nf)
 int nl_cap_for(int lpp) { return std::max(64 / lpp, 16); }
 
 // sort `n` particles given in arbitrary order into cell order on the device (context creation)
-void initial_sort(sphx_ctx *c, const Grid &g, int n, const double *x, const double *y, int *cellid, int *count,
-                  int *start, int *perm, const ReorderArgs &ra)
+void initial_sort(sphx_ctx *c, const Grid &g, int n, const double2 *pos, int *cellid, int *count, int *start, int *perm,
+                  const ReorderArgs &ra)
 {
     hipStream_t s = c->stream;
     if (n <= 0) {
         SPHX_HIP(hipMemsetAsync(start, 0, ((size_t)g.ncells + 1) * sizeof(int), s));
         return;
     }
-    hipLaunchKernelGGL(k_bin, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, g, n, x, y, cellid, count);
+    hipLaunchKernelGGL(k_bin, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, g, n, pos, cellid, count);
     hipLaunchKernelGGL(k_scan_only, dim3(1), dim3(kScanBlock), 0, s, (const Clock *)nullptr, 0, (const int *)count, start, g.ncells);
     hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
                        (const int *)cellid, count, (const int *)start, perm);
@@ -535,28 +518,15 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->n_blocks_particles = (int)div_up((size_t)cap * c->lpp, kBlock);
     c->n_blocks_flat = (int)div_up((size_t)cap, kBlock);
     for (int k = 0; k < 2; ++k) {
-        c->fx_[k].alloc(cap); c->fy_[k].alloc(cap); c->fvx_[k].alloc(cap); c->fvy_[k].alloc(cap);
-        c->fdrho_[k].alloc(cap); c->fmass_[k].alloc(cap); c->fid_[k].alloc(cap);
-        c->fstart_[k].alloc((size_t)g.ncells + 1); c->fcell_[k].alloc(cap);
-        if (c->skin > 0.0) { c->fxb_[k].alloc(cap); c->fyb_[k].alloc(cap); }
+        c->fpos_[k].alloc(cap); c->fvel_[k].alloc(cap); c->fdrho_[k].alloc(cap); c->fmass_[k].alloc(cap);
+        c->fid_[k].alloc(cap); c->fstart_[k].alloc((size_t)g.ncells + 1); c->fcell_[k].alloc(cap);
+        if (c->skin > 0.0) c->fposb_[k].alloc(cap);
     }
-    DevBuf<double> *dbl[] = {&c->xn, &c->yn, &c->vxn, &c->vyn, &c->drhon, &c->rho, &c->Vol, &c->rhoh, &c->ph, &c->b11,
-                             &c->b12, &c->b21, &c->b22, &c->fpx, &c->fpy, &c->ffx, &c->ffy, &c->rho_out, &c->p_out};
-    for (auto *b : dbl) { b->alloc(cap); b->zero(c->stream); }
-    // tiling of the neighbour passes: tile_cells (params.reserved) > 0 = LDS-tiled kernels with that many cells
-    // per tile (experimental: measured 1.4-2x SLOWER than the list-walking kernels at 0.5-6 M particles, see
-    // DESIGN.md); <= 0 = list-walking kernels
-    {
-        const int want = c->prm.reserved;
-        const double rows_fluid = std::max(1.0, c->prm.DH / (2.0 * c->prm.h));
-        const double per_cell = std::max(1.0, (double)c->nf / ((double)std::floor(c->prm.DL / (2.0 * c->prm.h)) * rows_fluid));
-        const int hcap = 512;
-        int ct = want > 0 ? want : (int)std::floor(hcap / (3.0 * 1.4 * per_cell)) - 2;
-        ct = std::max(1, std::min(ct, g.ncy));
-        c->tiled = want > 0;
-        c->tcfg = TileCfg{ct, (g.ncy + ct - 1) / ct, hcap};
-    }
-    c->n_vpart = c->tiled ? g.ncx * c->tcfg.nseg : c->n_blocks_particles;
+    c->posn.alloc(cap); c->veln.alloc(cap); c->ffp.alloc(cap); c->ff.alloc(cap); c->fa.alloc(cap); c->fB.alloc(cap);
+    c->drhon.alloc(cap); c->rho_out.alloc(cap); c->p_out.alloc(cap);
+    c->posn.zero(c->stream); c->veln.zero(c->stream); c->ffp.zero(c->stream); c->ff.zero(c->stream);
+    c->fa.zero(c->stream); c->fB.zero(c->stream); c->drhon.zero(c->stream); c->rho_out.zero(c->stream); c->p_out.zero(c->stream);
+    c->n_vpart = c->n_blocks_particles;
     c->vpart.alloc(c->n_vpart);
     c->vpart.zero(c->stream);
     c->dpart.alloc(c->n_vpart);
@@ -565,8 +535,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->count.zero(c->stream);
     const int nl_cap = nl_cap_for(c->lpp);
     const size_t stride = (size_t)c->n_blocks_particles * kBlock;  // one list column per launched lane
-    if (c->tiled) c->nl16.alloc(stride * nl_cap);
-    else c->nl_idx.alloc(stride * nl_cap);
+    c->nl_idx.alloc(stride * nl_cap);
     c->nl_cnt.alloc(stride);
     c->nl_cnt.zero(c->stream);
     c->flags.alloc(1);
@@ -574,11 +543,10 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->big_scan = g.ncells > kBigScanCells;
     c->n_tiles = (int)div_up((size_t)g.ncells, kScanBlock);
     c->tile.alloc(2 * ((size_t)c->n_tiles + 1));
-    c->tmp = FluidTmp{c->xn.get(), c->yn.get(), c->vxn.get(), c->vyn.get(), c->drhon.get(), c->rho.get(), c->Vol.get(),
-                      c->rhoh.get(), c->ph.get(), c->b11.get(), c->b12.get(), c->b21.get(), c->b22.get(), c->fpx.get(),
-                      c->fpy.get(), c->ffx.get(), c->ffy.get(), c->rho_out.get(), c->p_out.get(), c->cellid.get(),
-                      c->count.get(), c->perm.get(), c->src_of.get(), c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(),
-                      c->flags.get(), c->tile.get(), (int)stride, nl_cap};
+    c->tmp = FluidTmp{c->posn.get(), c->veln.get(), c->drhon.get(), c->fa.get(), c->fB.get(), c->ffp.get(), c->ff.get(),
+                      c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
+                      c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
+                      (int)stride, nl_cap};
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
@@ -588,19 +556,20 @@ void upload_fluid(sphx_ctx *c, int n, const double *hx, const double *hy, const 
                   const double *hdrho, const double *hmass, const int *hid, bool wrap)
 {
     hipStream_t s = c->stream;
+    std::vector<double2> hp((size_t)std::max(n, 1)), hv((size_t)std::max(n, 1));
+    for (int i = 0; i < n; ++i) { hp[i] = make_double2(hx[i], hy[i]); hv[i] = make_double2(hvx[i], hvy[i]); }
     if (n > 0) {
-        c->xn.upload(hx, n, s); c->yn.upload(hy, n, s); c->vxn.upload(hvx, n, s); c->vyn.upload(hvy, n, s);
+        c->posn.upload(hp.data(), n, s); c->veln.upload(hv.data(), n, s);
         c->drhon.upload(hdrho, n, s);
         c->fmass_[1].upload(hmass, n, s);
         if (hid) c->fid_[1].upload(hid, n, s);
         else hipLaunchKernelGGL(k_iota, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, c->fid_[1].get(), 0);
-        if (wrap) hipLaunchKernelGGL(k_wrap_x, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, c->xn.get(), c->prm.DL);
+        if (wrap) hipLaunchKernelGGL(k_wrap_x, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, n, c->posn.get(), c->prm.DL);
     }
-    const double *src[6] = {c->xn.get(), c->yn.get(), c->vxn.get(), c->vyn.get(), c->drhon.get(), c->fmass_[1].get()};
     const FluidSet d = c->view(0, 0);
-    initial_sort(c, c->grid, n, c->xn.get(), c->yn.get(), c->cellid.get(), c->count.get(), d.start, c->perm.get(),
-                 reorder_args(src, c->fid_[1].get(), d, nullptr));
-    SPHX_HIP(hipStreamSynchronize(s));  // host staging vectors of the caller may die after this
+    initial_sort(c, c->grid, n, c->posn.get(), c->cellid.get(), c->count.get(), d.start, c->perm.get(),
+                 reorder_args(c->posn.get(), c->veln.get(), c->drhon.get(), c->fmass_[1].get(), c->fid_[1].get(), d, nullptr));
+    SPHX_HIP(hipStreamSynchronize(s));  // host staging vectors die after this
 }
 
 // upload nw wall particles (host SoA, x already in this context's frame) and sort them once
@@ -610,30 +579,31 @@ void upload_walls(sphx_ctx *c, int nw, const double *hx, const double *hy, const
     const Grid &g = c->grid;
     hipStream_t s = c->stream;
     const size_t nwz = nw > 0 ? (size_t)nw : 1;
-    c->wx.alloc(nwz); c->wy.alloc(nwz); c->wVol.alloc(nwz); c->wvx.alloc(nwz); c->wvy.alloc(nwz); c->wid.alloc(nwz);
+    c->wpos.alloc(nwz); c->wa.alloc(nwz); c->wid.alloc(nwz);
     c->wstart.alloc((size_t)g.ncells + 1); c->wrow_any.alloc(g.ncy);
-    DevBuf<double> tx(nwz), ty(nwz), tm(nwz), tV(nwz), tvx(nwz), tvy(nwz);
+    DevBuf<double2> tpos(nwz);
+    DevBuf<double4> ta(nwz);
     DevBuf<int> tid(nwz), tcell(nwz), tperm(nwz), tcount((size_t)g.ncells + 1);
     tcount.zero(s);
+    std::vector<double2> hp(nwz);
+    std::vector<double4> ha(nwz);
+    for (int i = 0; i < nw; ++i) {
+        hp[i] = make_double2(hx[i], hy[i]);
+        ha[i] = make_double4(hmass[i] / c->prm.rho0, hvx[i], hvy[i], 0.0);  // walls keep rho = rho0 (sph_physics_mex.c:214-216,233)
+    }
     if (nw > 0) {
-        tx.upload(hx, nw, s); ty.upload(hy, nw, s); tm.upload(hmass, nw, s); tvx.upload(hvx, nw, s); tvy.upload(hvy, nw, s);
-        tid.upload(hid, nw, s);
-        if (wrap) hipLaunchKernelGGL(k_wrap_x, dim3(div_up(nw, kBlock)), dim3(kBlock), 0, s, nw, tx.get(), c->prm.DL);
-        hipLaunchKernelGGL(k_wall_volume, dim3(div_up(nw, kBlock)), dim3(kBlock), 0, s, nw, (const double *)tm.get(),
-                           c->prm.rho0, tV.get());
+        tpos.upload(hp.data(), nw, s); ta.upload(ha.data(), nw, s); tid.upload(hid, nw, s);
+        if (wrap) hipLaunchKernelGGL(k_wrap_x, dim3(div_up(nw, kBlock)), dim3(kBlock), 0, s, nw, tpos.get(), c->prm.DL);
     }
     ReorderArgs ra{};
-    ra.nd = 5;
-    const double *src[5] = {tx.get(), ty.get(), tV.get(), tvx.get(), tvy.get()};
-    double *dst[5] = {c->wx.get(), c->wy.get(), c->wVol.get(), c->wvx.get(), c->wvy.get()};
-    for (int f = 0; f < 5; ++f) { ra.src[f] = src[f]; ra.dst[f] = dst[f]; }
+    ra.n2 = 1; ra.src2[0] = tpos.get(); ra.dst2[0] = c->wpos.get();
+    ra.n4 = 1; ra.src4[0] = ta.get(); ra.dst4[0] = c->wa.get();
     ra.id_src = tid.get(); ra.id_dst = c->wid.get(); ra.src_of = nullptr; ra.cell_dst = nullptr;
-    initial_sort(c, g, nw, tx.get(), ty.get(), tcell.get(), tcount.get(), c->wstart.get(), tperm.get(), ra);
+    initial_sort(c, g, nw, tpos.get(), tcell.get(), tcount.get(), c->wstart.get(), tperm.get(), ra);
     hipLaunchKernelGGL(k_row_any, dim3(div_up(g.ncy, 64)), dim3(64), 0, s, g, (const int *)c->wstart.get(), c->wrow_any.get());
     SPHX_HIP(hipGetLastError());
     SPHX_HIP(hipStreamSynchronize(s));  // temporaries die here
-    c->walls = Walls{c->wx.get(), c->wy.get(), c->wVol.get(), c->wvx.get(), c->wvy.get(), c->wid.get(),
-                     c->wstart.get(), c->wrow_any.get(), nw};
+    c->walls = Walls{c->wpos.get(), c->wa.get(), c->wid.get(), c->wstart.get(), c->wrow_any.get(), nw};
 }
 
 void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
@@ -647,8 +617,8 @@ void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
     *c->h_clock = k;
     SPHX_HIP(hipMemcpyAsync(c->clock.get(), c->h_clock, sizeof(Clock), hipMemcpyHostToDevice, s));
     SPHX_HIP(hipStreamSynchronize(s));
-    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, s, c->clock.get(), c->grid, (const double *)c->fx_[0].get(),
-                       (const double *)c->fvx_[0].get(), (const double *)c->fvy_[0].get(), (double *)nullptr);
+    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, s, c->clock.get(), c->grid, (const double2 *)c->fpos_[0].get(),
+                       (const double2 *)c->fvel_[0].get(), (double *)nullptr);
     SPHX_HIP(hipGetLastError());
     c->cur = 0; c->lay = 0; c->pos = 0; c->out_lay = 0;
     set_epoch(c);
@@ -690,7 +660,6 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     const double *px = pos, *py = pos + ntz;
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
-    if (prm->lanes_per_particle <= 0 && prm->reserved > 0) c->lpp = std::max(c->lpp, 2);
     check_lpp(c->lpp);
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 16;
     if (c->spg & 1) c->spg += 1;
@@ -704,7 +673,6 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // step), 60 k 93.9 -> 80.2, 0.5 M 343 -> 316, 6 M 4101 -> 3907 (the wider cells lengthen the candidate sweeps
     // by ~10 %, the scatter/reorder kernels run on every fifth step only).
     int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : 5;
-    if (prm->reserved > 0) K = 1;  // the LDS-tiled kernels bin by position
     const double d_step = 0.035 * prm->h;
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
     if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
@@ -923,11 +891,13 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
     DevBuf<double> stage((size_t)4 * nt);
     const dim3 gf(div_up(nf, kBlock)), gw(div_up(std::max(nw, 1), kBlock)), b(kBlock);
     auto col = [&](int cidx) { return stage.get() + (size_t)cidx * nt; };
-    auto unsort_f = [&](const int *id, const double *src, int cidx) {
-        hipLaunchKernelGGL(k_unsort, gf, b, 0, s, nf, id, src, col(cidx));
+    // component `comp` of a field stored as records of `stride` doubles
+    auto unsort_f = [&](const int *id, const void *src, int stride, int comp, int cidx) {
+        hipLaunchKernelGGL(k_unsort, gf, b, 0, s, nf, id, (const double *)src + comp, stride, col(cidx));
     };
-    auto unsort_w = [&](const double *src, int cidx) {
-        if (nw > 0) hipLaunchKernelGGL(k_unsort, gw, b, 0, s, nw, (const int *)c->wid.get(), src, col(cidx));
+    auto unsort_w = [&](const void *src, int stride, int comp, int cidx) {
+        if (nw > 0)
+            hipLaunchKernelGGL(k_unsort, gw, b, 0, s, nw, (const int *)c->wid.get(), (const double *)src + comp, stride, col(cidx));
     };
     auto fill_w = [&](int cidx, double v) {
         if (nw > 0) hipLaunchKernelGGL(k_fill, gw, b, 0, s, nw, col(cidx) + nf, v);
@@ -936,16 +906,20 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
         SPHX_HIP(hipMemcpyAsync(host, stage.get(), (size_t)ncol * nt * sizeof(double), hipMemcpyDeviceToHost, s));
         SPHX_HIP(hipStreamSynchronize(s));
     };
-    if (pos) { unsort_f(fs.id, fs.x, 0); unsort_f(fs.id, fs.y, 1); unsort_w(c->wx.get(), 0); unsort_w(c->wy.get(), 1); out(pos, 2); }
-    if (vel) { unsort_f(fs.id, fs.vx, 0); unsort_f(fs.id, fs.vy, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(vel, 2); }
-    if (drho_dt) { unsort_f(fs.id, fs.drho, 0); fill_w(0, 0.0); out(drho_dt, 1); }
-    if (rho) { unsort_f(id_old, c->rho_out.get(), 0); fill_w(0, c->prm.rho0); out(rho, 1); }
-    if (p) { unsort_f(id_old, c->p_out.get(), 0); fill_w(0, 0.0); out(p, 1); }
-    if (force) { unsort_f(id_old, c->ffx.get(), 0); unsort_f(id_old, c->ffy.get(), 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force, 2); }
-    if (force_prior) { unsort_f(id_old, c->fpx.get(), 0); unsort_f(id_old, c->fpy.get(), 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force_prior, 2); }
-    if (Vol) { unsort_f(id_old, c->Vol.get(), 0); unsort_w(c->wVol.get(), 0); out(Vol, 1); }
+    if (pos) {
+        unsort_f(fs.id, fs.pos, 2, 0, 0); unsort_f(fs.id, fs.pos, 2, 1, 1);
+        unsort_w(c->wpos.get(), 2, 0, 0); unsort_w(c->wpos.get(), 2, 1, 1);
+        out(pos, 2);
+    }
+    if (vel) { unsort_f(fs.id, fs.vel, 2, 0, 0); unsort_f(fs.id, fs.vel, 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(vel, 2); }
+    if (drho_dt) { unsort_f(fs.id, fs.drho, 1, 0, 0); fill_w(0, 0.0); out(drho_dt, 1); }
+    if (rho) { unsort_f(id_old, c->rho_out.get(), 1, 0, 0); fill_w(0, c->prm.rho0); out(rho, 1); }
+    if (p) { unsort_f(id_old, c->p_out.get(), 1, 0, 0); fill_w(0, 0.0); out(p, 1); }
+    if (force) { unsort_f(id_old, c->ff.get(), 2, 0, 0); unsort_f(id_old, c->ff.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force, 2); }
+    if (force_prior) { unsort_f(id_old, c->ffp.get(), 2, 0, 0); unsort_f(id_old, c->ffp.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force_prior, 2); }
+    if (Vol) { unsort_f(id_old, c->fa.get(), 4, 0, 0); unsort_w(c->wa.get(), 4, 0, 0); out(Vol, 1); }
     if (B) {
-        unsort_f(id_old, c->b11.get(), 0); unsort_f(id_old, c->b12.get(), 1); unsort_f(id_old, c->b21.get(), 2); unsort_f(id_old, c->b22.get(), 3);
+        for (int k = 0; k < 4; ++k) unsort_f(id_old, c->fB.get(), 4, k, k);
         fill_w(0, 1.0); fill_w(1, 0.0); fill_w(2, 0.0); fill_w(3, 1.0);
         out(B, 4);
     }
@@ -1221,12 +1195,12 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
                  hf.id.data(), false);
     upload_walls(c, nw_local, hw.x.data(), hw.y.data(), hw.mass.data(), wvx.data(), wvy.data(), hw.id.data(), false);
 
-    c->kx.alloc(cap); c->ky.alloc(cap); c->kvx.alloc(cap); c->kvy.alloc(cap); c->kdrho.alloc(cap); c->kmass.alloc(cap);
+    c->kpos.alloc(cap); c->kvel.alloc(cap); c->kdrho.alloc(cap); c->kmass.alloc(cap);
     c->kid.alloc(cap); c->counters.alloc(3); c->n_new.alloc(1);
     c->counters.zero(c->stream);
     SlabPack p{};
     p.counters = c->counters.get();
-    p.kx = c->kx.get(); p.ky = c->ky.get(); p.kvx = c->kvx.get(); p.kvy = c->kvy.get(); p.kdrho = c->kdrho.get();
+    p.kpos = c->kpos.get(); p.kvel = c->kvel.get(); p.kdrho = c->kdrho.get();
     p.kmass = c->kmass.get(); p.kid = c->kid.get();
     p.halo_w = (double)H * csx;
     p.shift_l = (rank == 0) ? DL : 0.0;             // my left neighbour is the last slab: it sees me at x + DL
@@ -1310,8 +1284,8 @@ SPHX_EXPORT int sphx_slab_local_vmax(sphx_ctx *c, double *vmax_dev)
     SPHX_TRY
     require(c != nullptr && c->is_slab && vmax_dev != nullptr, "SPHX:Slab:ctx", "not a slab context");
     const FluidSet fs = c->view(c->cur, c->cur);
-    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, c->stream, c->clock.get(), c->grid, (const double *)fs.x,
-                       (const double *)fs.vx, (const double *)fs.vy, vmax_dev);
+    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, c->stream, c->clock.get(), c->grid, (const double2 *)fs.pos,
+                       (const double2 *)fs.vel, vmax_dev);
     SPHX_HIP(hipGetLastError());
     return SPHX_OK;
     SPHX_CATCH
@@ -1370,12 +1344,12 @@ SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
                vmax_global_dev, (const int *)c->flags.get(), (const int *)nullptr, (int *)nullptr, 0,
                (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0);
-        launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, q, c->grid, 0, (const double *)c->kx.get(),
-               (const double *)c->ky.get(), c->cellid.get(), c->count.get());
+        launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, q, c->grid, 0, (const double2 *)c->kpos.get(), c->cellid.get(),
+               c->count.get());
         const FluidSet d = c->view(1 - q, 1 - q);
         launch_cell_scan(c, clk, q, d.start);
-        const double *src[6] = {c->kx.get(), c->ky.get(), c->kvx.get(), c->kvy.get(), c->kdrho.get(), c->kmass.get()};
-        launch_scatter_reorder(c, clk, q, src, c->kid.get(), d, nullptr);
+        launch_scatter_reorder(c, clk, q,
+                               reorder_args(c->kpos.get(), c->kvel.get(), c->kdrho.get(), c->kmass.get(), c->kid.get(), d, nullptr), d);
         launch(c, "k_slab_reset", k_slab_reset, dim3(1), dim3(1), (const Clock *)clk, q, c->counters.get());
     };
     const void *key[3] = {recv_left_dev, recv_right_dev, vmax_global_dev};
@@ -1421,12 +1395,17 @@ SPHX_EXPORT int sphx_slab_snapshot(sphx_ctx *c, int capacity, int *n, double *x,
     auto dl = [&](const void *src, void *dst, size_t bytes) {
         if (dst && m) SPHX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
     };
-    std::vector<double> hx((size_t)std::max(m, 1));
-    dl(fs.x, hx.data(), (size_t)m * 8); dl(fs.x, x, (size_t)m * 8); dl(fs.y, y, (size_t)m * 8); dl(fs.vx, vx, (size_t)m * 8);
-    dl(fs.vy, vy, (size_t)m * 8); dl(fs.drho, drho, (size_t)m * 8); dl(fs.id, id, (size_t)m * 4);
+    std::vector<double2> hp((size_t)std::max(m, 1)), hv((size_t)std::max(m, 1));
+    dl(fs.pos, hp.data(), (size_t)m * 16); dl(fs.vel, hv.data(), (size_t)m * 16);
+    dl(fs.drho, drho, (size_t)m * 8); dl(fs.id, id, (size_t)m * 4);
     SPHX_HIP(hipStreamSynchronize(s));
-    if (owned)
-        for (int i = 0; i < m; ++i) owned[i] = (hx[i] >= c->grid.own_lo && hx[i] < c->grid.own_hi) ? 1 : 0;
+    for (int i = 0; i < m; ++i) {
+        if (x) x[i] = hp[i].x;
+        if (y) y[i] = hp[i].y;
+        if (vx) vx[i] = hv[i].x;
+        if (vy) vy[i] = hv[i].y;
+        if (owned) owned[i] = (hp[i].x >= c->grid.own_lo && hp[i].x < c->grid.own_hi) ? 1 : 0;
+    }
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -1444,10 +1423,10 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     require(!c->is_slab, "SPHX:Ctx:slab", "not available on a slab context");
     const std::string n(name);
     int only = 0;
-    if (n == "k_density" || n == "k_density_t") only = 1;
-    else if (n == "k_kgc" || n == "k_kgc_t") only = 2;
-    else if (n == "k_forces" || n == "k_forces_t") only = 3;
-    else if (n == "k_continuity" || n == "k_continuity_t") only = 4;
+    if (n == "k_density") only = 1;
+    else if (n == "k_kgc") only = 2;
+    else if (n == "k_forces") only = 3;
+    else if (n == "k_continuity") only = 4;
     require(only != 0, "SPHX:Ctx:kernel", "time_kernel knows k_density, k_kgc, k_forces, k_continuity");
     read_clock(c);
     if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);

@@ -41,13 +41,13 @@ def test_coincident_and_isolated_particles(cfgmod, geom, mex, oracle, capi):
     assert np.allclose(B[20], [1, 0, 0, 1])                          # det fallbacks -> identity
     # the resident loop keeps agreeing with the oracle on this state
     run = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=3, enable_sort=False)
-    for tile in (-1, 4):
+    for lpp in (1, 4):
         with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
-                          t_end=1e9, tile_cells=tile, lanes_per_particle=4) as ctx:
+                          t_end=1e9, lanes_per_particle=lpp) as ctx:
             ctx.advance(1e9, max_steps=3)
             out = ctx.download()
         for k in ("pos", "vel", "rho", "drho_dt", "B"):
-            assert_close(out[k], run[k], rtol=1e-9, atol_scale=1e-10, name=f"{k}/tile={tile}")
+            assert_close(out[k], run[k], rtol=1e-9, atol_scale=1e-10, name=f"{k}/lpp={lpp}")
 
 
 def test_empty_pair_list(cfgmod, geom, mex, oracle):

@@ -13,19 +13,18 @@ from helpers import assert_close, canon_pairs, make_case
 pytestmark = pytest.mark.gpu
 
 
-# (dp, DL, jitter, lanes per particle, cells per LDS tile: -1 = list-walking kernels, >0 = LDS-tiled kernels)
-@pytest.fixture(scope="module", params=[(0.05, 3.0, 0.2, 16, -1), (0.04, 3.0, 0.3, 1, -1), (0.025, 1.5, 0.25, 4, -1),
-                                        (0.05, 3.0, 0.2, 2, 3), (0.025, 1.5, 0.25, 1, 7), (0.04, 3.0, 0.3, 4, 32)])
+# (dp, DL, jitter, lanes per particle)
+@pytest.fixture(scope="module", params=[(0.05, 3.0, 0.2, 16), (0.04, 3.0, 0.3, 1), (0.025, 1.5, 0.25, 4),
+                                        (0.05, 3.0, 0.2, 2), (0.025, 1.5, 0.25, 32), (0.04, 3.0, 0.3, 8)])
 def case(request, cfgmod, geom):
-    dp, DL, jit, lpp, tile = request.param
+    dp, DL, jit, lpp = request.param
     prm, parts = make_case(cfgmod, geom, dp=dp, DL=DL, jitter=jit, seed=7, developed=True)
-    return prm, parts, (lpp, tile)
+    return prm, parts, lpp
 
 
 def _ctx(capi, prm, parts, lpp, **kw):
-    lpp, tile = lpp if isinstance(lpp, tuple) else (lpp, -1)
     return capi.Context(prm, parts["n_fluid"], parts["n_total"], parts["pos"], parts["vel"], parts["drho_dt"],
-                        parts["mass"], parts["wall_vel"], lanes_per_particle=lpp, tile_cells=tile, **kw)
+                        parts["mass"], parts["wall_vel"], lanes_per_particle=lpp, **kw)
 
 
 @pytest.mark.parametrize("n_steps", [1, 3, 10])
@@ -55,7 +54,7 @@ def test_bitwise_repeatable_and_lpp_consistent(case, capi):
     detector); different lanes-per-particle only change the summation tree (tiny differences)."""
     prm, parts, lpp = case
     outs = []
-    for l in (lpp, lpp, (8 if lpp[0] != 8 else 2, lpp[1])):
+    for l in (lpp, lpp, 8 if lpp != 8 else 2):
         with _ctx(capi, prm, parts, l, t_end=1e9) as ctx:
             ctx.advance(1e9, max_steps=6)
             outs.append(ctx.download(fields=("pos", "vel", "drho_dt")))
