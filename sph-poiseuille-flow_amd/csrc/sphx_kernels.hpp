@@ -84,6 +84,7 @@ struct FluidTmp {
     int *flags;      // [1] sticky device status bits (list overflow ...)
     int *tile_sum;   // big scan: per-tile sums / offsets
     int nl_stride, nl_cap;
+    int cap;         // particle capacity of every per-particle array (loads below it are always in bounds)
 };
 
 struct Walls {
@@ -195,6 +196,25 @@ __global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_st
 }
 
 // ---------------------------------------------------------------------------------------------
+// The neighbour list of a step.  Pass A sweeps the candidates (3 cell columns of fluid, and of wall
+// particles next to a wall) and packs the accepted ones into ONE list per particle: entry m belongs to
+// lane m % LPP, row m / LPP, so every lane owns ceil-or-floor(cnt / LPP) neighbours in the later passes
+// (balanced trip counts) and the lanes of a group walk adjacent particles.  Wall neighbours carry
+// kWallBit: passes B..E walk one list and never touch the cell structure again (at a few thousand
+// particles a pass is a chain of dependent memory round trips; cell -> row flag -> cell range -> wall
+// particle was three of them).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWallBit = 1 << 30;
+
+// Prologue shared by the passes: everything whose address does not depend on the clock is requested
+// BEFORE the run flag is looked at, so the clock read overlaps the particle's own loads.
+#define SPHX_PASS_INDEX()                                                  \
+    const int blk = xcd_block(blockIdx.x, gridDim.x);                      \
+    const int tid = blk * kBlock + threadIdx.x;                            \
+    const int i = tid / LPP, sub = tid % LPP;                              \
+    const bool in_cap = i < t.cap
+
+// ---------------------------------------------------------------------------------------------
 // pass A: candidate sweep -> neighbour list; number-density summation -> rho, Vol
 // (mex/sph_physics_mex.c:188-234) and the half-step density/pressure of integration_1st's pre-pass
 // (:857-862), which only needs own-particle data.
@@ -203,40 +223,62 @@ template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Grid g, Phys ph,
                                                     FluidSet s, FluidTmp t, Walls w)
 {
+    SPHX_PASS_INDEX();
+    const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const int ci = in_cap ? s.cell[i] : 0;
     if (!clk->run[q]) return;
-    const int n = clk->n;
-    const int blk = xcd_block(blockIdx.x, gridDim.x);
-    const int tid = blk * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
-    const bool active = i < n;
+    const bool active = i < clk->n;
     double s_in = 0.0, s_ct = 0.0;
     int cnt = 0;
-    // The LPP lanes of a particle test LPP consecutive candidates at a time; the accepted ones are packed
-    // (ballot + popcount) into ONE list per particle whose entry m belongs to lane m % LPP, row m / LPP.  Every
-    // lane then owns ceil-or-floor(cnt / LPP) neighbours in the later passes (balanced trip counts) and the lanes
-    // of a group walk adjacent particles, so a gather touches a few cache lines instead of ~27.
     if (active) {
-        const double2 pi = s.pos[i];
         const double xi = pi.x, yi = pi.y;
-        int cx, cy;
-        binned_cell(g, s, i, cx, cy);
+        const int cx = ci / g.ncy, cy = ci - cx * g.ncy;
         const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
         const int row_base = tid - sub;  // list column of lane 0 of this group
         const int cylo = max(cy - 1, 0), cyhi = min(cy + 1, g.ncy - 1);
+        const bool near_wall = w.row_any[cy] != 0;
+        // cell ranges of the three columns, fluid and wall, requested together
+        int lo[3], hi[3], wlo[3], whi[3];
 #pragma unroll
         for (int ox = -1; ox <= 1; ++ox) {
             int col = cx + ox;
+            bool ok = true;
             if (g.periodic) {
                 if (col < 0) col += g.ncx;
                 else if (col >= g.ncx) col -= g.ncx;
             } else if (col < 0 || col >= g.ncx) {
-                continue;
+                ok = false;
             }
-            const int lo = s.start[col * g.ncy + cylo], hi = s.start[col * g.ncy + cyhi + 1];
-            for (int kb = lo; kb < hi; kb += LPP) {  // uniform over the group
+            const int c0 = col * g.ncy + cylo, c1 = col * g.ncy + cyhi + 1;
+            lo[ox + 1] = ok ? s.start[c0] : 0;
+            hi[ox + 1] = ok ? s.start[c1] : 0;
+            wlo[ox + 1] = ok ? w.start[c0] : 0;
+            whi[ox + 1] = ok ? w.start[c1] : 0;
+        }
+        // the LPP lanes of a particle test LPP consecutive candidates at a time (uniform trip count over the
+        // group); accepted ones are packed with ballot + popcount
+        auto push = [&](bool acc, int entry) {
+            if (LPP == 1) {
+                if (acc) {
+                    if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = entry;
+                    ++cnt;
+                }
+            } else {
+                const unsigned long long bal = __ballot(acc);
+                const unsigned long long grp = (bal >> gbase) & ((1ull << LPP) - 1ull);
+                if (acc) {
+                    const int m = cnt + __popcll(grp & ((1ull << sub) - 1ull));
+                    if (m / LPP < t.nl_cap) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+                }
+                cnt += __popcll(grp);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            for (int kb = lo[c]; kb < hi[c]; kb += LPP) {
                 const int k = kb + sub;
                 bool acc = false;
-                if (k < hi) {
+                if (k < hi[c]) {
                     const double2 pj = s.pos[k];
                     const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                     const double r2 = dx * dx + dy * dy;
@@ -245,29 +287,28 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                         s_in += spline_W(ph.kc, r2 * rsqrt(r2));
                     }
                 }
-                if (LPP == 1) {
-                    if (acc) {
-                        if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = k;
-                        ++cnt;
-                    }
-                } else {
-                    const unsigned long long bal = __ballot(acc);
-                    const unsigned long long grp = (bal >> gbase) & ((1ull << LPP) - 1ull);
-                    if (acc) {
-                        const int m = cnt + __popcll(grp & ((1ull << sub) - 1ull));
-                        if (m / LPP < t.nl_cap) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = k;
-                    }
-                    cnt += __popcll(grp);
-                }
+                push(acc, k);
             }
         }
-        if (w.row_any[cy]) {
-            sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-                const double2 pj = w.pos[k];
-                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * w.a[k].x;
-            });
+        if (near_wall) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                for (int kb = wlo[c]; kb < whi[c]; kb += LPP) {
+                    const int k = kb + sub;
+                    bool acc = false;
+                    if (k < whi[c]) {
+                        const double2 pj = w.pos[k];
+                        const double Volj = w.a[k].x;  // requested with the position, not after the distance test
+                        const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
+                        const double r2 = dx * dx + dy * dy;
+                        if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                            acc = true;
+                            s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * Volj;
+                        }
+                    }
+                    push(acc, k | kWallBit);
+                }
+            }
         }
         if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
     }
@@ -288,23 +329,28 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
 
 // ---------------------------------------------------------------------------------------------
 // pass B: kernel-gradient-correction matrix A -> blended pseudo-inverse B
-// (mex/sph_physics_mex.c:239-366)
+// (mex/sph_physics_mex.c:239-366).  Fluid and wall neighbours contribute the same term (Vol_j of a wall
+// particle is m/rho0), so the walk does not branch.
 // ---------------------------------------------------------------------------------------------
 template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                 FluidTmp t, Walls w)
 {
+    SPHX_PASS_INDEX();
+    const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const int nn_all = t.nl_cnt[tid];
     if (!clk->run[q]) return;
-    const int n = clk->n;
-    const int blk = xcd_block(blockIdx.x, gridDim.x);
-    const int tid = blk * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
-    const bool active = i < n;
+    const bool active = i < clk->n;
     double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
     if (active) {
-        const double2 pi = s.pos[i];
         const double xi = pi.x, yi = pi.y;
-        auto term = [&](double dx, double dy, double Volj) {
+        for (int m = 0; m < nn_all; ++m) {
+            const int e = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            const bool wall = (e & kWallBit) != 0;
+            const int k = e & (kWallBit - 1);
+            const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
+            const double Volj = (wall ? w.a : (const double4 *)t.a)[k].x;
+            const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
             const double fxj = spline_dW(ph.kc, r) * Volj;
@@ -312,22 +358,6 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
             a12 -= dx * (fxj * ey);
             a21 -= dy * (fxj * ex);
             a22 -= dy * (fxj * ey);
-        };
-        const int nn = t.nl_cnt[tid];
-        for (int m = 0; m < nn; ++m) {
-            const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
-            const double2 pj = s.pos[k];
-            term(min_image(g, xi - pj.x), yi - pj.y, t.a[k].x);
-        }
-        int cx, cy;
-        binned_cell(g, s, i, cx, cy);
-        if (w.row_any[cy]) {
-            sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-                const double2 pj = w.pos[k];
-                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) term(dx, dy, w.a[k].x);
-            });
         }
     }
     a11 = group_sum<LPP>(a11);
@@ -344,86 +374,79 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
 // pass CD: viscous force (+gravity) [sph_physics_mex.c:469-545, SPH_Poiseuille.m:392], transport
 // shift [:636-710], Riemann pressure force of integration_1st [:870-957], velocity kick
 // [:1400-1408] and both position half-drifts [:863-864,:1066-1069] + periodic wrap
-// [SPH_Poiseuille.m:570-577].  One walk over the fluid ring serves all three operators because they
-// share e, dW, B_i+B_j; the wall ring is swept twice because the wall pressure needs the complete
-// viscous+gravity force of the particle first (p_wall uses force_prior_i, :931-934).
+// [SPH_Poiseuille.m:570-577].  One walk over the list serves all three operators because they share
+// e, dW, B_i+B_j; the wall entries are visited a second time because the wall pressure needs the
+// complete viscous+gravity force of the particle first (p_wall uses force_prior_i, :931-934).
 // ---------------------------------------------------------------------------------------------
 template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                    FluidTmp t, Walls w)
 {
+    SPHX_PASS_INDEX();
+    const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const double2 vi = in_cap ? s.vel[i] : make_double2(0.0, 0.0);
+    const double4 ai = in_cap ? t.a[i] : make_double4(1.0, 0.0, 0.0, 0.0);
+    const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
+    const double mi = in_cap ? s.mass[i] : 1.0;
+    const int nn_all = t.nl_cnt[tid];
     if (!clk->run[q]) return;
-    const int n = clk->n;
-    const int blk = xcd_block(blockIdx.x, gridDim.x);
-    const int tid = blk * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
-    const bool active = i < n;
+    const bool active = i < clk->n;
     const double h = ph.kc.h;
     double ax = 0.0, ay = 0.0, ix = 0.0, iy = 0.0, px = 0.0, py = 0.0, d2 = 0.0;
-    double xi = 0.0, yi = 0.0, vxi = 0.0, vyi = 0.0, Voli = 0.0, mi = 1.0, p_i = 0.0, rhoh_i = 0.0;
-    double b11i = 1.0, b12i = 0.0, b21i = 0.0, b22i = 1.0;
-    int cx = 0, cy = 0;
-    bool near_wall = false;
+    const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
+    const double Voli = ai.x, p_i = ai.y, rhoh_i = ai.z;
+    const double b11i = Bi.x, b12i = Bi.y, b21i = Bi.z, b22i = Bi.w;
+    int first_wall = 1 << 20;  // wall neighbours are appended behind the fluid ones: this lane's rows >= first_wall
     if (active) {
-        const double2 pi = s.pos[i], vi = s.vel[i];
-        const double4 ai = t.a[i], Bi = t.B[i];
-        xi = pi.x; yi = pi.y; vxi = vi.x; vyi = vi.y;
-        Voli = ai.x; mi = s.mass[i]; p_i = ai.y; rhoh_i = ai.z;
-        b11i = Bi.x; b12i = Bi.y; b21i = Bi.z; b22i = Bi.w;
-        const int nn = t.nl_cnt[tid];
-        for (int m = 0; m < nn; ++m) {
-            const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
-            const double2 pj = s.pos[k], vj = s.vel[k];
-            const double4 aj = t.a[k], Bj = t.B[k];
-            const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-            const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
-            const double ex = dx * inv_r, ey = dy * inv_r;
-            const double dW = spline_dW(ph.kc, r);
-            const double Volj = aj.x;
-            const double tx = (b11i + Bj.x) * ex + (b12i + Bj.y) * ey;
-            const double ty = (b21i + Bj.z) * ex + (b22i + Bj.w) * ey;
-            const double eBe = ex * tx + ey * ty;
-            const double vxj = vj.x, vyj = vj.y;
-            const double dWVj = dW * Volj;
-            // viscous
-            const double coeff = eBe * ph.mu * dWVj / (r + 0.01 * h);
-            ax += coeff * (vxi - vxj);
-            ay += coeff * (vyi - vyj);
-            // transport
-            ix -= dWVj * tx;
-            iy -= dWVj * ty;
-            // pressure (Riemann-dissipated face pressure)
-            const double p_j = aj.y;
-            const double rho_bar = 0.5 * (rhoh_i + aj.z);
-            const double un_l = vxi * ex + vyi * ey, un_r = vxj * ex + vyj * ey;
-            const double beta = riemann_beta(un_l, un_r, ph.c_f);
-            const double p_avg = 0.5 * (p_i + p_j);
-            const double p_star = p_avg + 0.5 * beta * rho_bar * (un_l - un_r);
-            const double p_face = 0.5 * (p_avg + p_star);
-            px -= (p_face * tx) * dWVj;
-            py -= (p_face * ty) * dWVj;
-        }
-        binned_cell(g, s, i, cx, cy);
-        near_wall = w.row_any[cy] != 0;
-        if (near_wall) {
-            sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-                const double2 pj = w.pos[k];
+        for (int m = 0; m < nn_all; ++m) {
+            const int e = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            const int k = e & (kWallBit - 1);
+            if (!(e & kWallBit)) {
+                const double2 pj = s.pos[k], vj = s.vel[k];
+                const double4 aj = t.a[k], Bj = t.B[k];
                 const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                    const double4 wj = w.a[k];
-                    const double inv_r = rsqrt(r2), r = r2 * inv_r;
-                    const double ex = dx * inv_r, ey = dy * inv_r;
-                    const double dWVj = spline_dW(ph.kc, r) * wj.x;
-                    const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
-                    const double eBe = ex * tx + ey * ty;
-                    const double coeff = 4.0 * eBe * ph.mu * dWVj / (r + 0.01 * h);
-                    ax += coeff * (vxi - wj.y);
-                    ay += coeff * (vyi - wj.z);
-                    ix -= 2.0 * dWVj * tx;
-                    iy -= 2.0 * dWVj * ty;
-                }
-            });
+                const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
+                const double ex = dx * inv_r, ey = dy * inv_r;
+                const double dW = spline_dW(ph.kc, r);
+                const double Volj = aj.x;
+                const double tx = (b11i + Bj.x) * ex + (b12i + Bj.y) * ey;
+                const double ty = (b21i + Bj.z) * ex + (b22i + Bj.w) * ey;
+                const double eBe = ex * tx + ey * ty;
+                const double vxj = vj.x, vyj = vj.y;
+                const double dWVj = dW * Volj;
+                // viscous
+                const double coeff = eBe * ph.mu * dWVj / (r + 0.01 * h);
+                ax += coeff * (vxi - vxj);
+                ay += coeff * (vyi - vyj);
+                // transport
+                ix -= dWVj * tx;
+                iy -= dWVj * ty;
+                // pressure (Riemann-dissipated face pressure)
+                const double p_j = aj.y;
+                const double rho_bar = 0.5 * (rhoh_i + aj.z);
+                const double un_l = vxi * ex + vyi * ey, un_r = vxj * ex + vyj * ey;
+                const double beta = riemann_beta(un_l, un_r, ph.c_f);
+                const double p_avg = 0.5 * (p_i + p_j);
+                const double p_star = p_avg + 0.5 * beta * rho_bar * (un_l - un_r);
+                const double p_face = 0.5 * (p_avg + p_star);
+                px -= (p_face * tx) * dWVj;
+                py -= (p_face * ty) * dWVj;
+            } else {
+                first_wall = min(first_wall, m);
+                const double2 pj = w.pos[k];
+                const double4 wj = w.a[k];
+                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
+                const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
+                const double ex = dx * inv_r, ey = dy * inv_r;
+                const double dWVj = spline_dW(ph.kc, r) * wj.x;
+                const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
+                const double eBe = ex * tx + ey * ty;
+                const double coeff = 4.0 * eBe * ph.mu * dWVj / (r + 0.01 * h);
+                ax += coeff * (vxi - wj.y);
+                ay += coeff * (vyi - wj.z);
+                ix -= 2.0 * dWVj * tx;
+                iy -= 2.0 * dWVj * ty;
+            }
         }
     }
     ax = group_sum<LPP>(ax);
@@ -432,23 +455,21 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     iy = group_sum<LPP>(iy);
     const double fpx = ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
     const double fpy = ay * Voli;
-    if (active && near_wall) {
+    if (active) {
         const double acx = fpx / mi, acy = fpy / mi;
-        sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
+        for (int m = first_wall; m < nn_all; ++m) {
+            const int k = t.nl_idx[(size_t)m * t.nl_stride + tid] & (kWallBit - 1);
             const double2 pj = w.pos[k];
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-            const double r2 = dx * dx + dy * dy;
-            if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                const double inv_r = rsqrt(r2), r = r2 * inv_r;
-                const double ex = dx * inv_r, ey = dy * inv_r;
-                const double dWVj = spline_dW(ph.kc, r) * w.a[k].x;
-                const double face = -(acx * ex + acy * ey);
-                const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
-                const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
-                px -= (p_i + p_wall) * dWVj * tx;
-                py -= (p_i + p_wall) * dWVj * ty;
-            }
-        });
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
+            const double ex = dx * inv_r, ey = dy * inv_r;
+            const double dWVj = spline_dW(ph.kc, r) * w.a[k].x;
+            const double face = -(acx * ex + acy * ey);
+            const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
+            const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
+            px -= (p_i + p_wall) * dWVj * tx;
+            py -= (p_i + p_wall) * dWVj * ty;
+        }
     }
     px = group_sum<LPP>(px);
     py = group_sum<LPP>(py);
@@ -556,46 +577,29 @@ template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, Grid g, Phys ph,
                                                        FluidSet s, FluidTmp t, Walls w, int do_hist)
 {
+    SPHX_PASS_INDEX();
+    const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const double2 vi = in_cap ? t.veln[i] : make_double2(0.0, 0.0);
+    const int nn_all = t.nl_cnt[tid];
     if (!clk->run[q]) return;
-    const int n = clk->n;
-    const int blk = xcd_block(blockIdx.x, gridDim.x);
-    const int tid = blk * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
-    const bool active = i < n;
+    const bool active = i < clk->n;
     double rate = 0.0, v2 = 0.0;
-    double vxi = 0.0, vyi = 0.0, xi = 0.0;
+    const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
     if (active) {
-        const double2 pi = s.pos[i], vi = t.veln[i];
-        xi = pi.x;
-        const double yi = pi.y;
-        vxi = vi.x;
-        vyi = vi.y;
-        const int nn = t.nl_cnt[tid];
-        for (int m = 0; m < nn; ++m) {
-            const int k = t.nl_idx[(size_t)m * t.nl_stride + tid];
-            const double2 pj = s.pos[k], vj = t.veln[k];
+        for (int m = 0; m < nn_all; ++m) {
+            const int e = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            const bool wall = (e & kWallBit) != 0;
+            const int k = e & (kWallBit - 1);
+            const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
+            const double4 aj = (wall ? w.a : (const double4 *)t.a)[k];  // .x = Vol either way; wall: .y,.z = wall velocity
+            double2 vj;
+            if (wall) vj = make_double2(2.0 * aj.y - vxi, 2.0 * aj.z - vyi);  // mirrored wall velocity
+            else vj = t.veln[k];
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
             const double u_jump = (vxi - vj.x) * ex + (vyi - vj.y) * ey;
-            rate += u_jump * spline_dW(ph.kc, r) * t.a[k].x;
-        }
-        int cx, cy;
-        binned_cell(g, s, i, cx, cy);
-        if (w.row_any[cy]) {
-            sweep<LPP>(g, w.start, cx, cy, sub, [&](int k) {
-                const double2 pj = w.pos[k];
-                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-                const double r2 = dx * dx + dy * dy;
-                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                    const double4 wj = w.a[k];
-                    const double inv_r = rsqrt(r2), r = r2 * inv_r;
-                    const double ex = dx * inv_r, ey = dy * inv_r;
-                    const double vjx = 2.0 * wj.y - vxi, vjy = 2.0 * wj.z - vyi;
-                    const double jump = (vxi - vjx) * ex + (vyi - vjy) * ey;
-                    rate += jump * spline_dW(ph.kc, r) * wj.x;
-                }
-            });
+            rate += u_jump * spline_dW(ph.kc, r) * aj.x;
         }
     }
     rate = group_sum<LPP>(rate);

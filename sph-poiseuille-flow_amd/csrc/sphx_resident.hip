@@ -480,7 +480,8 @@ int pick_lpp(int nf)
     return lpp;
 }
 
-int nl_cap_for(int lpp) { return std::max(64 / lpp, 16); }
+// rows of the per-lane neighbour list: >= 96 entries per particle (fluid ring ~30-45 + wall ring up to ~20)
+int nl_cap_for(int lpp) { return std::max(96 / lpp, 16); }
 
 // sort `n` particles given in arbitrary order into cell order on the device (context creation)
 void initial_sort(sphx_ctx *c, const Grid &g, int n, const double2 *pos, int *cellid, int *count, int *start, int *perm,
@@ -546,7 +547,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->tmp = FluidTmp{c->posn.get(), c->veln.get(), c->drhon.get(), c->fa.get(), c->fB.get(), c->ffp.get(), c->ff.get(),
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
-                      (int)stride, nl_cap};
+                      (int)stride, nl_cap, cap};
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
