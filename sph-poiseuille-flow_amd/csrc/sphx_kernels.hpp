@@ -226,6 +226,9 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int ci = in_cap ? s.cell[i] : 0;
+    const bool lead = in_cap && sub == 0;  // the lane that finishes the particle
+    const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
+    const double dt = clk->dt;
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
     double s_in = 0.0, s_ct = 0.0;
@@ -273,41 +276,46 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                 cnt += __popcll(grp);
             }
         };
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            for (int kb = lo[c]; kb < hi[c]; kb += LPP) {
-                const int k = kb + sub;
+        // The three fluid ranges (and, next to a wall, the three wall ranges) are walked as ONE virtual index range:
+        // a group of 32 lanes then needs one or two trips instead of one or two per column, and each trip's
+        // loads are independent of the previous trip's packing.
+        const int n0 = hi[0] - lo[0], n1 = hi[1] - lo[1], n2 = hi[2] - lo[2];
+        const int nfl = n0 + n1 + n2;
+        for (int vb = 0; vb < nfl; vb += LPP) {
+            const int v = vb + sub;
+            bool acc = false;
+            int k = 0;
+            if (v < nfl) {
+                k = v < n0 ? lo[0] + v : (v < n0 + n1 ? lo[1] + (v - n0) : lo[2] + (v - n0 - n1));
+                const double2 pj = s.pos[k];
+                const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
+                const double r2 = dx * dx + dy * dy;
+                if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                    acc = true;
+                    s_in += spline_W(ph.kc, r2 * rsqrt(r2));
+                }
+            }
+            push(acc, k);
+        }
+        if (near_wall) {
+            const int w0 = whi[0] - wlo[0], w1 = whi[1] - wlo[1], w2 = whi[2] - wlo[2];
+            const int nwl = w0 + w1 + w2;
+            for (int vb = 0; vb < nwl; vb += LPP) {
+                const int v = vb + sub;
                 bool acc = false;
-                if (k < hi[c]) {
-                    const double2 pj = s.pos[k];
+                int k = 0;
+                if (v < nwl) {
+                    k = v < w0 ? wlo[0] + v : (v < w0 + w1 ? wlo[1] + (v - w0) : wlo[2] + (v - w0 - w1));
+                    const double2 pj = w.pos[k];
+                    const double Volj = w.a[k].x;  // requested with the position, not after the distance test
                     const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                         acc = true;
-                        s_in += spline_W(ph.kc, r2 * rsqrt(r2));
+                        s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * Volj;
                     }
                 }
-                push(acc, k);
-            }
-        }
-        if (near_wall) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                for (int kb = wlo[c]; kb < whi[c]; kb += LPP) {
-                    const int k = kb + sub;
-                    bool acc = false;
-                    if (k < whi[c]) {
-                        const double2 pj = w.pos[k];
-                        const double Volj = w.a[k].x;  // requested with the position, not after the distance test
-                        const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-                        const double r2 = dx * dx + dy * dy;
-                        if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-                            acc = true;
-                            s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * Volj;
-                        }
-                    }
-                    push(acc, k | kWallBit);
-                }
+                push(acc, k | kWallBit);
             }
         }
         if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
@@ -318,10 +326,9 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {
-        const double m = s.mass[i];
+        const double m = mass_i;
         const double rho = density_from_sigma(ph.w0 + s_in, s_ct, m, ph.rho0, ph.inv_sigma0);
-        const double dt = clk->dt;
-        double rhoh = rho + 0.5 * dt * s.drho[i];
+        double rhoh = rho + 0.5 * dt * drho_i;
         if (rhoh < 1e-10) rhoh = ph.rho0;
         t.a[i] = make_double4(m / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho);
     }
@@ -389,6 +396,9 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
     const double mi = in_cap ? s.mass[i] : 1.0;
     const int nn_all = t.nl_cnt[tid];
+    const bool tracked = s.posb != nullptr;
+    const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
+    const double dt = clk->dt;
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
     const double h = ph.kc.h;
@@ -474,7 +484,6 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     px = group_sum<LPP>(px);
     py = group_sum<LPP>(py);
     if (active && sub == 0) {
-        const double dt = clk->dt;
         const double fx = px * Voli, fy = py * Voli;
         const double inv_m = 1.0 / mi;
         const double vxn = vxi + (fpx + fx) * inv_m * dt;
@@ -486,8 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         yo += 0.5 * dt * vyi;
         xo += 0.5 * dt * vxn;
         yo += 0.5 * dt * vyn;
-        if (s.posb) {
-            const double2 pb = s.posb[i];
+        if (tracked) {
             const double ddx = min_image(g, xo - pb.x), ddy = yo - pb.y;
             d2 = ddx * ddx + ddy * ddy;
             if (d2 != d2) d2 = INFINITY;
@@ -581,6 +589,10 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? t.veln[i] : make_double2(0.0, 0.0);
     const int nn_all = t.nl_cnt[tid];
+    const bool lead = in_cap && sub == 0;
+    const double rhoh_i = lead ? t.a[i].z : 0.0;
+    const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);
+    const double dt = clk->dt;
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
     double rate = 0.0, v2 = 0.0;
@@ -604,8 +616,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     }
     rate = group_sum<LPP>(rate);
     if (active && sub == 0) {
-        const double dt = clk->dt;
-        const double rhoh = t.a[i].z;
+        const double rhoh = rhoh_i;
         const double drho_new = rate * rhoh;
         double rho = rhoh + drho_new * (0.5 * dt);
         if (rho < 1e-10) rho = ph.rho0;
@@ -618,7 +629,6 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
         }
         if (do_hist) {
             int cx, cy;
-            const double2 pn = t.posn[i];
             cell_of(g, pn.x, pn.y, cx, cy);
             const int c = cx * g.ncy + cy;
             t.cellid[i] = c;
@@ -732,15 +742,17 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
                                                            int *start_next, int n_scan, const int *n_new,
                                                            const double *dpart, int rebuilt, double half_skin)
 {
-    if (!clk->run[q]) {
-        if (threadIdx.x == 0) clk->run[1 - q] = 0;
-        return;
-    }
+    // the partial maxima are requested before the run flag is looked at (stale values are harmless when the
+    // slot turns out to be idle)
     double m = 0.0, d = 0.0;
     if (!vmax_global)
         for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
     if (dpart)
         for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) d = fmax(d, dpart[k]);
+    if (!clk->run[q]) {
+        if (threadIdx.x == 0) clk->run[1 - q] = 0;
+        return;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); d = fmax(d, __shfl_xor(d, off)); }
     __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64];
