@@ -84,6 +84,12 @@ struct FluidTmp {
     int *flags;      // [1] sticky device status bits (list overflow ...)
     int *tile_sum;   // big scan: per-tile sums / offsets
     int nl_stride, nl_cap;
+    // Superset list (contexts that re-bin every K-th step): every pair within 2h + skin at binning time, same
+    // lane-major layout.  Built by pass A of the first step after a re-bin; the other steps of the cycle walk it
+    // (~1.3x the true neighbours) instead of sweeping cells (~3.7x).
+    int *sl_idx, *sl_cnt;
+    int sl_cap;
+    double sl_rcut2;  // (2h + skin)^2
     int cap;         // particle capacity of every per-particle array (loads below it are always in bounds)
 };
 
@@ -219,7 +225,9 @@ constexpr int kWallBit = 1 << 30;
 // (mex/sph_physics_mex.c:188-234) and the half-step density/pressure of integration_1st's pre-pass
 // (:857-862), which only needs own-particle data.
 // ---------------------------------------------------------------------------------------------
-template <int LPP>
+// MODE 0: sweep the cells, write the step's list.  MODE 1: same sweep, also write the superset list.
+// MODE 2: walk the superset list instead of the cells.
+template <int LPP, int MODE>
 __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Grid g, Phys ph,
                                                     FluidSet s, FluidTmp t, Walls w)
 {
@@ -232,12 +240,72 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
     double s_in = 0.0, s_ct = 0.0;
-    int cnt = 0;
-    if (active) {
+    int cnt = 0, scnt = 0;
+    const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
+    const int row_base = tid - sub;  // list column of lane 0 of this group
+    // the LPP lanes of a particle test LPP consecutive candidates at a time (uniform trip count over the
+    // group); accepted ones are packed with ballot + popcount
+    auto push = [&](bool acc, int entry) {
+        if (LPP == 1) {
+            if (acc) {
+                if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = entry;
+                ++cnt;
+            }
+        } else {
+            const unsigned long long bal = __ballot(acc);
+            const unsigned long long grp = (bal >> gbase) & ((1ull << LPP) - 1ull);
+            if (acc) {
+                const int m = cnt + __popcll(grp & ((1ull << sub) - 1ull));
+                if (m / LPP < t.nl_cap) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+            }
+            cnt += __popcll(grp);
+        }
+    };
+    auto push_super = [&](bool acc, int entry) {
+        if (LPP == 1) {
+            if (acc) {
+                if (scnt < t.sl_cap) t.sl_idx[(size_t)scnt * t.nl_stride + tid] = entry;
+                ++scnt;
+            }
+        } else {
+            const unsigned long long bal = __ballot(acc);
+            const unsigned long long grp = (bal >> gbase) & ((1ull << LPP) - 1ull);
+            if (acc) {
+                const int m = scnt + __popcll(grp & ((1ull << sub) - 1ull));
+                if (m / LPP < t.sl_cap) t.sl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+            }
+            scnt += __popcll(grp);
+        }
+    };
+    if (MODE == 2) {
+        const int ns = t.sl_cnt[tid];
+        const int rows = LPP == 1 ? ns : __shfl(ns, gbase);  // lane 0 of the group owns the most rows
+        if (active) {
+            const double xi = pi.x, yi = pi.y;
+            for (int m = 0; m < rows; ++m) {
+                bool acc = false;
+                int e = 0;
+                if (m < ns) {
+                    e = t.sl_idx[(size_t)m * t.nl_stride + tid];
+                    const bool wall = (e & kWallBit) != 0;
+                    const int k = e & (kWallBit - 1);
+                    const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
+                    const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
+                    const double r2 = dx * dx + dy * dy;
+                    if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                        acc = true;
+                        const double W = spline_W(ph.kc, r2 * rsqrt(r2));
+                        if (wall) s_ct += W * w.a[k].x;
+                        else s_in += W;
+                    }
+                }
+                push(acc, e);
+            }
+            if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
+        }
+    } else if (active) {
         const double xi = pi.x, yi = pi.y;
         const int cx = ci / g.ncy, cy = ci - cx * g.ncy;
-        const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
-        const int row_base = tid - sub;  // list column of lane 0 of this group
         const int cylo = max(cy - 1, 0), cyhi = min(cy + 1, g.ncy - 1);
         const bool near_wall = w.row_any[cy] != 0;
         // cell ranges of the three columns, fluid and wall, requested together
@@ -258,24 +326,6 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
             wlo[ox + 1] = ok ? w.start[c0] : 0;
             whi[ox + 1] = ok ? w.start[c1] : 0;
         }
-        // the LPP lanes of a particle test LPP consecutive candidates at a time (uniform trip count over the
-        // group); accepted ones are packed with ballot + popcount
-        auto push = [&](bool acc, int entry) {
-            if (LPP == 1) {
-                if (acc) {
-                    if (cnt < t.nl_cap) t.nl_idx[(size_t)cnt * t.nl_stride + tid] = entry;
-                    ++cnt;
-                }
-            } else {
-                const unsigned long long bal = __ballot(acc);
-                const unsigned long long grp = (bal >> gbase) & ((1ull << LPP) - 1ull);
-                if (acc) {
-                    const int m = cnt + __popcll(grp & ((1ull << sub) - 1ull));
-                    if (m / LPP < t.nl_cap) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
-                }
-                cnt += __popcll(grp);
-            }
-        };
         // The three fluid ranges (and, next to a wall, the three wall ranges) are walked as ONE virtual index range:
         // a group of 32 lanes then needs one or two trips instead of one or two per column, and each trip's
         // loads are independent of the previous trip's packing.
@@ -283,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
         const int nfl = n0 + n1 + n2;
         for (int vb = 0; vb < nfl; vb += LPP) {
             const int v = vb + sub;
-            bool acc = false;
+            bool acc = false, wide = false;
             int k = 0;
             if (v < nfl) {
                 k = v < n0 ? lo[0] + v : (v < n0 + n1 ? lo[1] + (v - n0) : lo[2] + (v - n0 - n1));
@@ -294,15 +344,17 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                     acc = true;
                     s_in += spline_W(ph.kc, r2 * rsqrt(r2));
                 }
+                wide = r2 > kR2Min && r2 < t.sl_rcut2;
             }
             push(acc, k);
+            if (MODE == 1) push_super(wide, k);
         }
         if (near_wall) {
             const int w0 = whi[0] - wlo[0], w1 = whi[1] - wlo[1], w2 = whi[2] - wlo[2];
             const int nwl = w0 + w1 + w2;
             for (int vb = 0; vb < nwl; vb += LPP) {
                 const int v = vb + sub;
-                bool acc = false;
+                bool acc = false, wide = false;
                 int k = 0;
                 if (v < nwl) {
                     k = v < w0 ? wlo[0] + v : (v < w0 + w1 ? wlo[1] + (v - w0) : wlo[2] + (v - w0 - w1));
@@ -314,15 +366,19 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                         acc = true;
                         s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * Volj;
                     }
+                    wide = r2 > kR2Min && r2 < t.sl_rcut2;
                 }
                 push(acc, k | kWallBit);
+                if (MODE == 1) push_super(wide, k | kWallBit);
             }
         }
         if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
+        if (MODE == 1 && scnt > t.sl_cap * LPP) { atomicOr(t.flags, 1); scnt = t.sl_cap * LPP; }
     }
     // cnt is the particle's neighbour count (identical in all lanes of the group); lane `sub` owns entries
     // sub, sub+LPP, ...
     if (tid < t.nl_stride) t.nl_cnt[tid] = cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0;
+    if (MODE == 1 && tid < t.nl_stride) t.sl_cnt[tid] = scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0;
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {

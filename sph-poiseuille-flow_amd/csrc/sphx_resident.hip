@@ -96,7 +96,7 @@ struct sphx_ctx {
     DevBuf<double2> posn, veln, ffp, ff;
     DevBuf<double4> fa, fB;
     DevBuf<double> drhon, rho_out, p_out, vpart, dpart;
-    DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, flags, tile;
+    DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, sl_idx, sl_cnt, flags, tile;
     DevBuf<double2> wpos;
     DevBuf<double4> wa;
     DevBuf<int> wid, wstart, wrow_any;
@@ -211,26 +211,32 @@ ReorderArgs reorder_args(const double2 *pos, const double2 *vel, const double *d
 
 // The four neighbour passes on state view `s`, writing the end-of-step state through t.xn/yn/vxn/vyn/drhon.
 // only: 0 = all four, 1..4 = just density / kgc / forces / continuity (kernel timing)
+// dmode: 0 = pass A sweeps the cells; 1 = sweeps and writes the superset list (first step after a re-bin);
+//        2 = walks the superset list
 template <int LPP>
-void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only)
+void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
-    if (!only || only == 1) launch(c, "k_density", k_density<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+    if (!only || only == 1) {
+        if (dmode == 0) launch(c, "k_density", k_density<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        else if (dmode == 1) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        else launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+    }
     if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
     if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
     if (!only || only == 4) launch(c, "k_continuity", k_continuity<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, do_hist);
 }
 
-void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0)
+void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0, int dmode = 0)
 {
     switch (c->lpp) {
-        case 1: launch_physics<1>(c, q, s, t, do_hist, only); break;
-        case 2: launch_physics<2>(c, q, s, t, do_hist, only); break;
-        case 4: launch_physics<4>(c, q, s, t, do_hist, only); break;
-        case 8: launch_physics<8>(c, q, s, t, do_hist, only); break;
-        case 16: launch_physics<16>(c, q, s, t, do_hist, only); break;
-        case 32: launch_physics<32>(c, q, s, t, do_hist, only); break;
+        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode); break;
+        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode); break;
+        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode); break;
+        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode); break;
+        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode); break;
+        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode); break;
         default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
     }
 }
@@ -263,9 +269,10 @@ void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderA
 
 // One single-GPU step slot: state S[q], layout L[l].  rebuild: the step ends with re-binning into S[1-q], L[1-l]
 // (7 launches); otherwise the passes write the new state straight into S[1-q] and the layout stays (5 launches).
-void launch_step(sphx_ctx *c, int q, int l, bool rebuild)
+void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
 {
     Clock *clk = c->clock.get();
+    const int dmode = c->skin > 0.0 ? (pos == 0 ? 1 : 2) : 0;
     const FluidSet s = c->view(q, l);
     const bool track = c->skin > 0.0;
     const double *dpart = track ? (const double *)c->dpart.get() : nullptr;
@@ -273,13 +280,13 @@ void launch_step(sphx_ctx *c, int q, int l, bool rebuild)
         FluidTmp t = c->tmp;
         const FluidSet o = c->view(1 - q, l);
         t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
-        launch_physics_any(c, q, s, t, 0);
+        launch_physics_any(c, q, s, t, 0, 0, dmode);
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
                (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(), (const int *)nullptr,
                (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin());
         return;
     }
-    launch_physics_any(c, q, s, c->tmp, 1);
+    launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
     const FluidSet d = c->view(1 - q, 1 - l);
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
@@ -338,7 +345,7 @@ void build_graph(sphx_ctx *c)
     c->profiling = false;
     SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     try {
-        for (int j = 0; j < n; ++j) launch_step(c, j & 1, (j / K) & 1, (j % K) == K - 1);
+        for (int j = 0; j < n; ++j) launch_step(c, j & 1, (j / K) & 1, j % K, (j % K) == K - 1);
     } catch (...) {
         hipGraph_t junk = nullptr;
         (void)hipStreamEndCapture(c->stream, &junk);
@@ -373,7 +380,7 @@ void enqueue_slots(sphx_ctx *c, int64_t slots)
             c->out_lay = 1;
             continue;
         }
-        launch_step(c, c->cur, c->lay, slot_rebuilds(c));
+        launch_step(c, c->cur, c->lay, c->pos, slot_rebuilds(c));
         track_step(c);
         --left;
     }
@@ -539,6 +546,13 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->nl_idx.alloc(stride * nl_cap);
     c->nl_cnt.alloc(stride);
     c->nl_cnt.zero(c->stream);
+    const int sl_cap = c->skin > 0.0 ? (3 * nl_cap + 1) / 2 : 0;
+    if (sl_cap) {
+        c->sl_idx.alloc(stride * sl_cap);
+        c->sl_cnt.alloc(stride);
+        c->sl_cnt.zero(c->stream);
+    }
+    const double sl_r = 2.0 * c->prm.h + c->skin;
     c->flags.alloc(1);
     c->flags.zero(c->stream);
     c->big_scan = g.ncells > kBigScanCells;
@@ -547,7 +561,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->tmp = FluidTmp{c->posn.get(), c->veln.get(), c->drhon.get(), c->fa.get(), c->fB.get(), c->ffp.get(), c->ff.get(),
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
-                      (int)stride, nl_cap, cap};
+                      (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap};
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
@@ -1424,7 +1438,7 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     require(!c->is_slab, "SPHX:Ctx:slab", "not available on a slab context");
     const std::string n(name);
     int only = 0;
-    if (n == "k_density") only = 1;
+    if (n == "k_density" || n == "k_density_build" || n == "k_density_walk") only = 1;
     else if (n == "k_kgc") only = 2;
     else if (n == "k_forces") only = 3;
     else if (n == "k_continuity") only = 4;
@@ -1441,9 +1455,10 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end, (long long)1,
                            c->cur, (const double *)nullptr);
         const FluidSet fs = c->view(c->cur, c->lay);
-        launch_physics_any(c, c->cur, fs, c->tmp, 0, 0);  // make every temporary the timed kernel reads valid
+        const int dmode = c->skin > 0.0 ? (c->pos == 0 ? 1 : 2) : 0;
+        launch_physics_any(c, c->cur, fs, c->tmp, 0, 0, dmode);  // make every temporary the timed kernel reads valid
         SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, fs, c->tmp, 0, only);
+        for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, fs, c->tmp, 0, only, dmode);
         SPHX_HIP(hipStreamEndCapture(c->stream, &g));
         SPHX_HIP(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
         SPHX_HIP(hipGraphLaunch(e, c->stream));  // warm
