@@ -607,11 +607,9 @@ __device__ __forceinline__ int block_exclusive_scan_t(int v, int &total, int *s_
 
 // advance the device clock by the step that has just been computed (one thread)
 // drift: largest distance from the binning positions (< 0: not tracked); rebuilt: this step ends with a fresh grid.
-__device__ __forceinline__ void clock_step(Clock *clk, int q, const Phys &ph, double vmax, const int *flags,
-                                           const int *n_new, double drift = -1.0, int rebuilt = 1,
-                                           double half_skin = 0.0)
+__device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phys &ph, double vmax, int flags,
+                                           int n_new, double drift = -1.0, int rebuilt = 1, double half_skin = 0.0)
 {
-    Clock c = *clk;
     if (drift >= 0.0) {
         c.drift = rebuilt ? 0.0 : drift;
         // every step sweeps the cells the particles were BINNED into; that finds all neighbours only while no
@@ -624,8 +622,8 @@ __device__ __forceinline__ void clock_step(Clock *clk, int q, const Phys &ph, do
     c.step += 1;
     if (c.steps_left > 0) c.steps_left -= 1;
     if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
-    if (*flags) c.status = SPHX_ERR_GRID;  // neighbour-list / slab-buffer overflow
-    if (n_new) c.n = *n_new;
+    if (flags) c.status = SPHX_ERR_GRID;  // neighbour-list / slab-buffer overflow
+    if (n_new >= 0) c.n = n_new;
     c.dt = next_dt(c, ph);
     c.run[1 - q] = loop_continues(c) ? 1 : 0;
     *clk = c;
@@ -798,8 +796,17 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
                                                            int *start_next, int n_scan, const int *n_new,
                                                            const double *dpart, int rebuilt, double half_skin)
 {
-    // the partial maxima are requested before the run flag is looked at (stale values are harmless when the
-    // slot turns out to be idle)
+    // everything is requested before the run flag is looked at (stale values are harmless when the slot turns
+    // out to be idle); only the thread that advances the clock loads it
+    Clock c0;
+    int fl = 0, nn = -1;
+    double vg = 0.0;
+    if (threadIdx.x == 0) {
+        c0 = *clk;
+        fl = *flags;
+        if (n_new) nn = *n_new;
+        if (vmax_global) vg = *vmax_global;
+    }
     double m = 0.0, d = 0.0;
     if (!vmax_global)
         for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
@@ -817,8 +824,7 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
     if (threadIdx.x == 0) {
         for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
         // max of sqrt == sqrt of max (monotone, correctly rounded)
-        clock_step(clk, q, ph, vmax_global ? *vmax_global : sqrt(m), flags, n_new, dpart ? sqrt(d) : -1.0, rebuilt,
-                   half_skin);
+        clock_step(clk, c0, q, ph, vmax_global ? vg : sqrt(m), fl, nn, dpart ? sqrt(d) : -1.0, rebuilt, half_skin);
     }
     if (count) scan_counts(count, start_next, n_scan);
 }
