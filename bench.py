@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_FLUID = {"k_density": 40, "k_kgc": 56, "k_forces": 112 + 192, "k_continuity": 104,
                    "k_clock_scan": 0, "k_scatter": 8, "k_reorder": 16}
 BYTES_PER_WALL = {"k_density": 24, "k_kgc": 24, "k_forces": 48, "k_continuity": 24}
+for _k in ("_build", "_walk"):  # pass A sweeping cells + recording the superset list / walking the superset list
+    BYTES_PER_FLUID["k_density" + _k] = BYTES_PER_FLUID["k_density"]
+    BYTES_PER_WALL["k_density" + _k] = BYTES_PER_WALL["k_density"]
 STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
 
 
@@ -83,7 +86,7 @@ def pmc_traffic(name, kernel):
     2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of MI355X_MICROARCH.md applied); None if not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[name][kernel.replace("_t", "")]["traffic_bytes"]
+            return json.load(f)[name][kernel]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -122,7 +125,7 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
         kernels = ctx.profile_read()
         ctx.profile_enable(False)
         if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+            dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])  # most device time
             ms_eager = kernels[dom]["avg_ms"]
             try:  # the dominant kernel alone, back-to-back in a replayed graph: the regime of the timed region
                 ms = ctx.time_kernel(dom, reps=max(20, min(400, int(0.05 / max(ms_eager * 1e-3, 1e-7)))))
