@@ -236,6 +236,14 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     const int ci = in_cap ? s.cell[i] : 0;
     const bool lead = in_cap && sub == 0;  // the lane that finishes the particle
     const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
+    // list-walking variant: row count and the first two rows are requested here as well (a lane rarely owns more
+    // at 32 lanes per particle): count -> entry -> position becomes {count, entries} -> position
+    int ns = 0, e_row0 = 0, e_row1 = 0;
+    if (MODE == 2) {
+        ns = t.sl_cnt[tid];
+        e_row0 = t.sl_idx[tid];
+        e_row1 = t.sl_idx[(size_t)t.nl_stride + tid];
+    }
     const double dt = clk->dt;
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
@@ -278,7 +286,6 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
         }
     };
     if (MODE == 2) {
-        const int ns = t.sl_cnt[tid];
         const int rows = LPP == 1 ? ns : __shfl(ns, gbase);  // lane 0 of the group owns the most rows
         if (active) {
             const double xi = pi.x, yi = pi.y;
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                 bool acc = false;
                 int e = 0;
                 if (m < ns) {
-                    e = t.sl_idx[(size_t)m * t.nl_stride + tid];
+                    e = m == 0 ? e_row0 : (m == 1 ? e_row1 : t.sl_idx[(size_t)m * t.nl_stride + tid]);
                     const bool wall = (e & kWallBit) != 0;
                     const int k = e & (kWallBit - 1);
                     const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
@@ -402,13 +409,16 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int nn_all = t.nl_cnt[tid];
+    // the first two rows are requested together with the count (at 32 lanes per particle a lane rarely owns more):
+    // count -> entry -> neighbour data becomes {count, entries} -> neighbour data
+    const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
     double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
     if (active) {
         const double xi = pi.x, yi = pi.y;
         for (int m = 0; m < nn_all; ++m) {
-            const int e = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : t.nl_idx[(size_t)m * t.nl_stride + tid]);
             const bool wall = (e & kWallBit) != 0;
             const int k = e & (kWallBit - 1);
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
@@ -452,6 +462,9 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
     const double mi = in_cap ? s.mass[i] : 1.0;
     const int nn_all = t.nl_cnt[tid];
+    // the first two rows are requested together with the count (at 32 lanes per particle a lane rarely owns more):
+    // count -> entry -> neighbour data becomes {count, entries} -> neighbour data
+    const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
     const bool tracked = s.posb != nullptr;
     const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
     const double dt = clk->dt;
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     int first_wall = 1 << 20;  // wall neighbours are appended behind the fluid ones: this lane's rows >= first_wall
     if (active) {
         for (int m = 0; m < nn_all; ++m) {
-            const int e = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : t.nl_idx[(size_t)m * t.nl_stride + tid]);
             const int k = e & (kWallBit - 1);
             if (!(e & kWallBit)) {
                 const double2 pj = s.pos[k], vj = s.vel[k];
@@ -643,6 +656,9 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? t.veln[i] : make_double2(0.0, 0.0);
     const int nn_all = t.nl_cnt[tid];
+    // the first two rows are requested together with the count (at 32 lanes per particle a lane rarely owns more):
+    // count -> entry -> neighbour data becomes {count, entries} -> neighbour data
+    const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
     const bool lead = in_cap && sub == 0;
     const double rhoh_i = lead ? t.a[i].z : 0.0;
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);
@@ -653,7 +669,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
     if (active) {
         for (int m = 0; m < nn_all; ++m) {
-            const int e = t.nl_idx[(size_t)m * t.nl_stride + tid];
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : t.nl_idx[(size_t)m * t.nl_stride + tid]);
             const bool wall = (e & kWallBit) != 0;
             const int k = e & (kWallBit - 1);
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
