@@ -409,16 +409,17 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int nn_all = t.nl_cnt[tid];
-    // the first two rows are requested together with the count (at 32 lanes per particle a lane rarely owns more):
-    // count -> entry -> neighbour data becomes {count, entries} -> neighbour data
+    // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
+    // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
+    const int e_row2 = t.nl_idx[2 * (size_t)t.nl_stride + tid], e_row3 = t.nl_idx[3 * (size_t)t.nl_stride + tid];
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
     double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
     if (active) {
         const double xi = pi.x, yi = pi.y;
         for (int m = 0; m < nn_all; ++m) {
-            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : t.nl_idx[(size_t)m * t.nl_stride + tid]);
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (m == 2 ? e_row2 : (m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
             const bool wall = (e & kWallBit) != 0;
             const int k = e & (kWallBit - 1);
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
@@ -462,9 +463,10 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
     const double mi = in_cap ? s.mass[i] : 1.0;
     const int nn_all = t.nl_cnt[tid];
-    // the first two rows are requested together with the count (at 32 lanes per particle a lane rarely owns more):
-    // count -> entry -> neighbour data becomes {count, entries} -> neighbour data
+    // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
+    // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
+    const int e_row2 = t.nl_idx[2 * (size_t)t.nl_stride + tid], e_row3 = t.nl_idx[3 * (size_t)t.nl_stride + tid];
     const bool tracked = s.posb != nullptr;
     const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
     const double dt = clk->dt;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     int first_wall = 1 << 20;  // wall neighbours are appended behind the fluid ones: this lane's rows >= first_wall
     if (active) {
         for (int m = 0; m < nn_all; ++m) {
-            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : t.nl_idx[(size_t)m * t.nl_stride + tid]);
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (m == 2 ? e_row2 : (m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
             const int k = e & (kWallBit - 1);
             if (!(e & kWallBit)) {
                 const double2 pj = s.pos[k], vj = s.vel[k];
@@ -656,9 +658,10 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? t.veln[i] : make_double2(0.0, 0.0);
     const int nn_all = t.nl_cnt[tid];
-    // the first two rows are requested together with the count (at 32 lanes per particle a lane rarely owns more):
-    // count -> entry -> neighbour data becomes {count, entries} -> neighbour data
+    // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
+    // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
+    const int e_row2 = t.nl_idx[2 * (size_t)t.nl_stride + tid], e_row3 = t.nl_idx[3 * (size_t)t.nl_stride + tid];
     const bool lead = in_cap && sub == 0;
     const double rhoh_i = lead ? t.a[i].z : 0.0;
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
     if (active) {
         for (int m = 0; m < nn_all; ++m) {
-            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : t.nl_idx[(size_t)m * t.nl_stride + tid]);
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (m == 2 ? e_row2 : (m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
             const bool wall = (e & kWallBit) != 0;
             const int k = e & (kWallBit - 1);
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
