@@ -805,6 +805,31 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(const Clock *clk, int q
     if (idx == 0) start[n] = tile_off[n_tiles];
 }
 
+// Millions of particles leave ~10^5 per-block maxima; one workgroup reading them all took 84 us at 6 M particles.
+// This pre-pass folds kMaxTile of them per workgroup (max is exact, so the result does not depend on the split).
+constexpr int kMaxTile = 4096;
+__global__ __launch_bounds__(kScanBlock) void k_max_tiles(const Clock *clk, int q, int n, const double *a, const double *b,
+                                                          double *out_a, double *out_b)
+{
+    if (!clk->run[q]) return;
+    const int base = blockIdx.x * kMaxTile;
+    double m = 0.0, d = 0.0;
+    for (int k = base + threadIdx.x; k < min(base + kMaxTile, n); k += kScanBlock) {
+        m = fmax(m, a[k]);
+        if (b) d = fmax(d, b[k]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); d = fmax(d, __shfl_xor(d, off)); }
+    __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
+        out_a[blockIdx.x] = m;
+        if (b) out_b[blockIdx.x] = d;
+    }
+}
+
 // Step kernel 5: finish the clock of this step (vmax -> next dt, t += dt, stop test) and scan the
 // cell histogram (small grids) or the tile sums (big grids).  Single block.
 //   vmax_global: slab mode -- the all-reduced max |v| replaces the local reduction.

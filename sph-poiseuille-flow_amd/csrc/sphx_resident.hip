@@ -95,7 +95,8 @@ struct sphx_ctx {
     DevBuf<int> fid_[2], fstart_[2], fcell_[2];
     DevBuf<double2> posn, veln, ffp, ff;
     DevBuf<double4> fa, fB;
-    DevBuf<double> drhon, rho_out, p_out, vpart, dpart;
+    DevBuf<double> drhon, rho_out, p_out, vpart, dpart, vtile;
+    int n_vtiles = 0;            // > 0: k_max_tiles folds the per-block maxima first (very many blocks)
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, sl_idx, sl_cnt, flags, tile;
     DevBuf<double2> wpos;
     DevBuf<double4> wa;
@@ -276,28 +277,43 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     const FluidSet s = c->view(q, l);
     const bool track = c->skin > 0.0;
     const double *dpart = track ? (const double *)c->dpart.get() : nullptr;
+    // what k_clock_scan reduces: the per-block maxima, or (many blocks) their per-tile maxima
+    const double *vsrc = c->vpart.get();
+    int n_red = c->n_vpart;
+    auto pre_reduce = [&]() {
+        if (c->n_vtiles == 0) return;
+        launch(c, "k_max_tiles", k_max_tiles, dim3(c->n_vtiles), dim3(kScanBlock), (const Clock *)clk, q, c->n_vpart,
+               (const double *)c->vpart.get(), dpart, c->vtile.get(), c->vtile.get() + c->n_vtiles);
+    };
+    if (c->n_vtiles) {
+        vsrc = c->vtile.get();
+        if (dpart) dpart = c->vtile.get() + c->n_vtiles;
+        n_red = c->n_vtiles;
+    }
     if (!rebuild) {
         FluidTmp t = c->tmp;
         const FluidSet o = c->view(1 - q, l);
         t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
         launch_physics_any(c, q, s, t, 0, 0, dmode);
-        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
-               (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(), (const int *)nullptr,
+        pre_reduce();
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
+               vsrc, (const double *)nullptr, (const int *)c->flags.get(), (const int *)nullptr,
                (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin());
         return;
     }
     launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
+    pre_reduce();
     const FluidSet d = c->view(1 - q, 1 - l);
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
-        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
-               (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(),
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
+               vsrc, (const double *)nullptr, (const int *)c->flags.get(),
                (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr, dpart, 1, c->half_skin());
     } else {
         int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
         launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
                (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
-        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, c->n_vpart,
-               (const double *)c->vpart.get(), (const double *)nullptr, (const int *)c->flags.get(), (const int *)tile_sum,
+        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
+               vsrc, (const double *)nullptr, (const int *)c->flags.get(), (const int *)tile_sum,
                tile_off, c->n_tiles, (const int *)nullptr, dpart, 1, c->half_skin());
         launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                (const int *)tile_off, c->grid.ncells, c->n_tiles);
@@ -539,6 +555,8 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->vpart.zero(c->stream);
     c->dpart.alloc(c->n_vpart);
     c->dpart.zero(c->stream);
+    c->n_vtiles = (!c->is_slab && c->n_vpart > 4 * kMaxTile) ? (int)div_up((size_t)c->n_vpart, kMaxTile) : 0;
+    if (c->n_vtiles) c->vtile.alloc(2 * (size_t)c->n_vtiles);
     c->cellid.alloc(cap); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(cap); c->src_of.alloc(cap);
     c->count.zero(c->stream);
     const int nl_cap = nl_cap_for(c->lpp);
