@@ -280,10 +280,11 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     // what k_clock_scan reduces: the per-block maxima, or (many blocks) their per-tile maxima
     const double *vsrc = c->vpart.get();
     int n_red = c->n_vpart;
-    auto pre_reduce = [&]() {
+    const double *dpart_blocks = dpart;  // the per-block array (dpart is redirected to the tiles below)
+    auto pre_reduce = [c, clk, q, dpart_blocks]() {
         if (c->n_vtiles == 0) return;
         launch(c, "k_max_tiles", k_max_tiles, dim3(c->n_vtiles), dim3(kScanBlock), (const Clock *)clk, q, c->n_vpart,
-               (const double *)c->vpart.get(), dpart, c->vtile.get(), c->vtile.get() + c->n_vtiles);
+               (const double *)c->vpart.get(), dpart_blocks, c->vtile.get(), c->vtile.get() + c->n_vtiles);
     };
     if (c->n_vtiles) {
         vsrc = c->vtile.get();
