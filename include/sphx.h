@@ -141,7 +141,7 @@ typedef struct sphx_params {
     double rho0, mu, c_f, p0, inv_sigma0, gravity_g;
     double transport_coeff; /* 0.30 in the main loop (:77); 0.2 reproduces advance_shell_step        */
     double t_end;           /* loop bound, SPH_Poiseuille.m:247                                     */
-    int32_t sort_interval;  /* kept for signature parity; the device re-sorts by cell every step     */
+    int32_t sort_interval;  /* kept for signature parity; the device keeps cell order (see rebuild_every) */
     int32_t lanes_per_particle; /* 0 = auto; 1,2,4,8,16,32: lanes cooperating on one neighbour ring */
     int32_t steps_per_graph;    /* 0 = auto; steps captured per hipGraph replay (even)               */
     int32_t reserved;           /* must be 0                                                         */

@@ -210,7 +210,7 @@ ReorderArgs reorder_args(const double2 *pos, const double2 *vel, const double *d
     return ra;
 }
 
-// The four neighbour passes on state view `s`, writing the end-of-step state through t.xn/yn/vxn/vyn/drhon.
+// The four neighbour passes on state view `s`, writing the end-of-step state through t.posn / veln / drhon.
 // only: 0 = all four, 1..4 = just density / kgc / forces / continuity (kernel timing)
 // dmode: 0 = pass A sweeps the cells; 1 = sweeps and writes the superset list (first step after a re-bin);
 //        2 = walks the superset list
