@@ -842,11 +842,14 @@ __global__ __launch_bounds__(kScanBlock) void k_max_tiles(const Clock *clk, int 
 // cell histogram (small grids) or the tile sums (big grids).  Single block.
 //   vmax_global: slab mode -- the all-reduced max |v| replaces the local reduction.
 //   dpart / rebuilt / half_skin: displacement bookkeeping of grids that are rebuilt only every few steps.
+//   slab_counters: slab mode -- the keep/left/right counters of k_slab_pack, zeroed for the next step (the unpack
+//   kernel of this step has read them).
 __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Phys ph, int n_vpart,
                                                            const double *vpart, const double *vmax_global,
                                                            const int *flags, const int *count,
                                                            int *start_next, int n_scan, const int *n_new,
-                                                           const double *dpart, int rebuilt, double half_skin)
+                                                           const double *dpart, int rebuilt, double half_skin,
+                                                           int *slab_counters)
 {
     // everything is requested before the run flag is looked at (stale values are harmless when the slot turns
     // out to be idle); only the thread that advances the clock loads it
@@ -877,6 +880,7 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
         for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
         // max of sqrt == sqrt of max (monotone, correctly rounded)
         clock_step(clk, c0, q, ph, vmax_global ? vg : sqrt(m), fl, nn, dpart ? sqrt(d) : -1.0, rebuilt, half_skin);
+        if (slab_counters) { slab_counters[0] = 0; slab_counters[1] = 0; slab_counters[2] = 0; }  // pack counters of the next step
     }
     if (count) scan_counts(count, start_next, n_scan);
 }
@@ -885,24 +889,6 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_only(const Clock *clk, int 
 {
     if (clk && !clk->run[q]) return;
     scan_counts(count, start, n);
-}
-
-// reduce per-block max |v|^2 to max |v| (slab: input of the all-reduce); single block
-__global__ __launch_bounds__(kScanBlock) void k_vmax_reduce(const Clock *clk, int q, int n_vpart, const double *vpart,
-                                                            double *vmax_out)
-{
-    if (clk && !clk->run[q]) { if (threadIdx.x == 0) *vmax_out = 0.0; return; }
-    double m = 0.0;
-    for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    __shared__ double s_m[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
-        *vmax_out = sqrt(m);
-    }
 }
 
 // Step kernel 6: place every particle index into its cell range (arrival order, made canonical by
@@ -1173,6 +1159,7 @@ struct SlabPack {
     double2 *kpos, *kvel;      // keep arrays (compacted)
     double *kdrho, *kmass;
     int *kid;
+    int *cellid, *count;       // cell of every kept / received particle and the cell histogram (binned on the fly)
     double halo_w, shift_l, shift_r, win_lo, win_hi;
     int msg_cap, keep_cap;
 };
@@ -1206,6 +1193,11 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(const Clock *clk, int q, G
         const int k = atomicAdd(&p.counters[0], 1);
         if (k < p.keep_cap) {
             p.kpos[k] = pn; p.kvel[k] = vn; p.kdrho[k] = dr; p.kmass[k] = m; p.kid[k] = id;
+            int cx, cy;
+            cell_of(g, xn, yn, cx, cy);
+            const int c = cx * g.ncy + cy;
+            p.cellid[k] = c;
+            atomicAdd(&p.count[c], 1);
         } else atomicOr(t.flags, 2);
     }
     if (xn < g.own_lo + p.halo_w) {
@@ -1220,16 +1212,32 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(const Clock *clk, int q, G
     }
 }
 
-// one thread: publish the message counts after the pack kernel
-__global__ void k_slab_seal(const Clock *clk, int q, SlabPack p)
+// after the pack kernel, one workgroup: publish the message counts and reduce the per-block max |v|^2 of the
+// owned particles to max |v| (input of the all-reduce)
+__global__ __launch_bounds__(kScanBlock) void k_slab_seal_vmax(const Clock *clk, int q, SlabPack p, int n_vpart,
+                                                               const double *vpart, double *vmax_out)
 {
     const bool run = clk->run[q] != 0;
-    p.send_l[0] = run ? (double)min(p.counters[1], p.msg_cap) : -1.0;
-    p.send_r[0] = run ? (double)min(p.counters[2], p.msg_cap) : -1.0;
+    if (threadIdx.x == 0) {
+        p.send_l[0] = run ? (double)min(p.counters[1], p.msg_cap) : -1.0;
+        p.send_r[0] = run ? (double)min(p.counters[2], p.msg_cap) : -1.0;
+    }
+    if (!run) { if (threadIdx.x == 0) *vmax_out = 0.0; return; }
+    double m = 0.0;
+    for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    __shared__ double s_m[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kScanBlock / 64; ++k) m = fmax(m, s_m[k]);
+        *vmax_out = sqrt(m);
+    }
 }
 
 // append the received halo/migrant particles behind the kept ones; writes the new particle count.
-__global__ __launch_bounds__(kBlock) void k_slab_unpack(const Clock *clk, int q, SlabPack p, const double *recv_l,
+__global__ __launch_bounds__(kBlock) void k_slab_unpack(const Clock *clk, int q, Grid g, SlabPack p, const double *recv_l,
                                                         const double *recv_r, int *n_new, int *flags)
 {
     if (!clk->run[q]) return;
@@ -1246,19 +1254,18 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const Clock *clk, int q,
         const double *b = (i < nl ? recv_l : recv_r) + 1;
         const int sl = i < nl ? i : i - nl;
         const int d = nk + i;
-        p.kpos[d] = make_double2(b[sl], b[(size_t)cap + sl]);
+        const double x = b[sl], y = b[(size_t)cap + sl];
+        p.kpos[d] = make_double2(x, y);
+        int cx, cy;
+        cell_of(g, x, y, cx, cy);
+        const int c = cx * g.ncy + cy;
+        p.cellid[d] = c;
+        atomicAdd(&p.count[c], 1);
         p.kvel[d] = make_double2(b[2 * (size_t)cap + sl], b[3 * (size_t)cap + sl]);
         p.kdrho[d] = b[4 * (size_t)cap + sl];
         p.kmass[d] = b[5 * (size_t)cap + sl];
         p.kid[d] = (int)b[6 * (size_t)cap + sl];
     }
-}
-
-// one thread, after the rebuild of a slab step: zero the pack counters for the next step
-__global__ void k_slab_reset(const Clock *clk, int q, int *counters)
-{
-    if (!clk->run[q]) return;
-    counters[0] = 0; counters[1] = 0; counters[2] = 0;
 }
 
 }  // namespace sphx

@@ -299,7 +299,7 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         pre_reduce();
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(), (const int *)nullptr,
-               (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin());
+               (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin(), (int *)nullptr);
         return;
     }
     launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
@@ -308,14 +308,14 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(),
-               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr, dpart, 1, c->half_skin());
+               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr);
     } else {
         int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
         launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
                (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(), (const int *)tile_sum,
-               tile_off, c->n_tiles, (const int *)nullptr, dpart, 1, c->half_skin());
+               tile_off, c->n_tiles, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr);
         launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                (const int *)tile_off, c->grid.ncells, c->n_tiles);
     }
@@ -1236,6 +1236,7 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     p.counters = c->counters.get();
     p.kpos = c->kpos.get(); p.kvel = c->kvel.get(); p.kdrho = c->kdrho.get();
     p.kmass = c->kmass.get(); p.kid = c->kid.get();
+    p.cellid = c->cellid.get(); p.count = c->count.get();
     p.halo_w = (double)H * csx;
     p.shift_l = (rank == 0) ? DL : 0.0;             // my left neighbour is the last slab: it sees me at x + DL
     p.shift_r = (rank == n_ranks - 1) ? -DL : 0.0;  // my right neighbour is the first slab
@@ -1346,13 +1347,12 @@ SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *se
     const Clock *clk = c->clock.get();
     auto body = [&]() {
         launch_physics_any(c, q, c->view(q, q), c->tmp, 0);
-        launch(c, "k_vmax_reduce", k_vmax_reduce, dim3(1), dim3(kScanBlock), clk, q, c->n_vpart,
-               (const double *)c->vpart.get(), vmax_local_dev);
         SlabPack p = c->pack;
         p.send_l = send_left_dev;
         p.send_r = send_right_dev;
         launch(c, "k_slab_pack", k_slab_pack, dim3(c->n_blocks_flat), dim3(kBlock), clk, q, c->grid, c->view(q, q), c->tmp, p);
-        launch(c, "k_slab_seal", k_slab_seal, dim3(1), dim3(1), clk, q, p);
+        launch(c, "k_slab_seal_vmax", k_slab_seal_vmax, dim3(1), dim3(kScanBlock), clk, q, p, c->n_vpart,
+               (const double *)c->vpart.get(), vmax_local_dev);
     };
     const void *key[3] = {send_left_dev, send_right_dev, vmax_local_dev};
     slab_half(c, 0, q, key, body);
@@ -1371,20 +1371,29 @@ SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const
     Clock *clk = c->clock.get();
     const dim3 g1(c->n_blocks_flat), bp(kBlock);
     auto body = [&]() {
+        // kept particles were binned by the pack kernel, the received ones are binned here
         launch(c, "k_slab_unpack", k_slab_unpack, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), bp, (const Clock *)clk, q,
-               c->pack, recv_left_dev, recv_right_dev, c->n_new.get(), c->flags.get());
-        // clock: t += dt, new particle count, next dt from the global max |v|.  It arms run[1-q]; the remaining
-        // kernels of this slot still test run[q], and from here on clk->n is the new particle count.
-        launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
-               vmax_global_dev, (const int *)c->flags.get(), (const int *)nullptr, (int *)nullptr, 0,
-               (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0);
-        launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, q, c->grid, 0, (const double2 *)c->kpos.get(), c->cellid.get(),
-               c->count.get());
+               c->grid, c->pack, recv_left_dev, recv_right_dev, c->n_new.get(), c->flags.get());
+        // clock: t += dt, new particle count, next dt from the global max |v| -- and the scan of the cell histogram
+        // and the reset of the pack counters.  It arms run[1-q]; the remaining kernels of this slot still test
+        // run[q], and from here on clk->n is the new particle count.
         const FluidSet d = c->view(1 - q, 1 - q);
-        launch_cell_scan(c, clk, q, d.start);
+        if (!c->big_scan) {
+            launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
+                   vmax_global_dev, (const int *)c->flags.get(), (const int *)c->count.get(), d.start, c->grid.ncells,
+                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get());
+        } else {
+            int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
+            launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
+                   (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
+            launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
+                   vmax_global_dev, (const int *)c->flags.get(), (const int *)tile_sum, tile_off, c->n_tiles,
+                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get());
+            launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
+                   (const int *)tile_off, c->grid.ncells, c->n_tiles);
+        }
         launch_scatter_reorder(c, clk, q,
                                reorder_args(c->kpos.get(), c->kvel.get(), c->kdrho.get(), c->kmass.get(), c->kid.get(), d, nullptr), d);
-        launch(c, "k_slab_reset", k_slab_reset, dim3(1), dim3(1), (const Clock *)clk, q, c->counters.get());
     };
     const void *key[3] = {recv_left_dev, recv_right_dev, vmax_global_dev};
     slab_half(c, 1, q, key, body);

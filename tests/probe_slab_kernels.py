@@ -1,0 +1,51 @@
+"""Manual probe (not a test): per-kernel device time of one x-slab step, two ranks sharing one GPU over gloo.
+    SPHX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29533 tests/probe_slab_kernels.py [dp DL]"""
+import ctypes as C
+import importlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("sph-poiseuille-flow_amd")
+slab = importlib.import_module("sph-poiseuille-flow_amd.slab")
+capi, cfg, geo = pkg.capi, pkg.config, pkg.geometry
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    dp = float(sys.argv[1]) if len(sys.argv) > 1 else 0.025
+    DL = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    prm = cfg.params_from_values(end_time=1e9, dp=dp, DL=DL)
+    parts = geo.init_particles(prm)
+    pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
+    eng = slab.HipSlabEngine(prm, parts, rank, world, 0, t_end=1e9, pos=pos, vel=vel)
+    drv = slab.SlabDriver(eng, slab.RingExchange(rank, world))
+    drv.run_steps(50)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drv.run_steps(200)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 200
+    capi.check(capi.lib().sphx_ctx_profile_enable(eng._h, C.c_int(1)))
+    drv.run_steps(50)
+    cap = 64
+    names = (C.c_char_p * cap)()
+    avg = (C.c_double * cap)()
+    cnt = (C.c_int64 * cap)()
+    n = C.c_int(0)
+    capi.check(capi.lib().sphx_ctx_profile_read(eng._h, C.c_int(cap), names, avg, cnt, C.byref(n)))
+    if rank == 0:
+        ks = {names[k].decode(): round(avg[k] * 1e3, 1) for k in range(n.value)}
+        print(f"dp={dp} DL={DL} n_total={parts['n_total']} layout={eng.layout()} wall us/step (gloo, host staged) {wall*1e6:.1f}")
+        print("per-kernel us (eager):", ks, "sum", round(sum(ks.values()), 1), flush=True)
+    eng.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
