@@ -77,11 +77,14 @@ class RingExchange:
 
     def _p2p(self, send_l, send_r, recv_l, recv_r):
         dist = self.dist
-        ops = [dist.P2POp(dist.isend, send_l, self.left, group=self.group, tag=0),
-               dist.P2POp(dist.isend, send_r, self.right, group=self.group, tag=1),
-               dist.P2POp(dist.irecv, recv_r, self.right, group=self.group, tag=0),
-               dist.P2POp(dist.irecv, recv_l, self.left, group=self.group, tag=1)]
-        for req in dist.batch_isend_irecv(ops):
+        key = (send_l.data_ptr(), send_r.data_ptr(), recv_l.data_ptr(), recv_r.data_ptr())
+        if getattr(self, "_ops_key", None) != key:  # the four buffers are fixed: build the op list once, not per step
+            self._ops = [dist.P2POp(dist.isend, send_l, self.left, group=self.group, tag=0),
+                         dist.P2POp(dist.isend, send_r, self.right, group=self.group, tag=1),
+                         dist.P2POp(dist.irecv, recv_r, self.right, group=self.group, tag=0),
+                         dist.P2POp(dist.irecv, recv_l, self.left, group=self.group, tag=1)]
+            self._ops_key = key
+        for req in dist.batch_isend_irecv(self._ops):
             req.wait()
 
     def reduce_max(self, vmax):
