@@ -9,11 +9,11 @@ Nothing here falls back to the CPU: compute entry points need csrc/libsphx.so an
 """
 from . import config, geometry, profile  # noqa: F401  (pure host logic, importable without the .so)
 
-__all__ = ["config", "geometry", "profile", "capi", "mex_surface", "driver", "build"]
+__all__ = ["config", "geometry", "profile", "restart", "capi", "mex_surface", "driver", "build"]
 
 
 def __getattr__(name):
-    if name in ("capi", "mex_surface", "driver", "build", "slab"):
+    if name in ("capi", "mex_surface", "driver", "build", "slab", "restart"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

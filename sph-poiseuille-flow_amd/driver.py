@@ -18,6 +18,7 @@ import numpy as np
 from . import capi
 from .geometry import init_particles
 from .mex_surface import sph_neighbor_search_mex, sph_physics_shell_mex
+from . import restart
 from .profile import compute_mid_channel_profile, final_profile, l2_error, n_profile_bins
 
 
@@ -64,10 +65,26 @@ def periodic_bounding(pos, n_fluid, DL):
 
 
 def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_particle=0, steps_per_graph=0,
-        rebuild_every=0):
-    """Run to prm.t_end and return the final profile and L2 (SPH_Poiseuille.m:246-307 + postprocess :42)."""
+        rebuild_every=0, restart_path=None, postprocess_path=None):
+    """Run to prm.t_end and return the final profile and L2 (SPH_Poiseuille.m:246-307 + postprocess :42).
+
+    restart_path (resident engine): the reference's restart.mat protocol -- resume from it when
+    prm.restart_from_file is set and its signature / sizes match (:132-163), rewrite it at every output point
+    (:295).  postprocess_path: write SPH_Poiseuille_postprocess.mat at the end (:305-306)."""
     parts = init_particles(prm) if parts is None else parts
     nf, nt = parts["n_fluid"], parts["n_total"]
+    t_start, step_start = 0.0, 0
+    if restart_path and engine != "resident":
+        raise ValueError("restart files are handled by the resident engine")
+    if restart_path and prm.restart_from_file:
+        st, why = restart.load_restart(restart_path, nt, prm.config_signature)
+        if st is not None:
+            parts = dict(parts, pos=st["pos"], vel=st["vel"], drho_dt=st["drho_dt"])
+            t_start, step_start = st["t"], st["step"]
+            if log:
+                log(f"Restart: resuming from t={t_start:.6f}, step={step_start}")
+        elif log:
+            log(f"Restart file not used ({why}); starting from scratch")
     n_bins = n_profile_bins(prm.DH, prm.dp)
     mid_x, mid_hw = 0.5 * prm.DL, max(prm.dp, prm.h)
     profile_times, mid_profiles = [0.0], []
@@ -78,9 +95,9 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
     t0 = time.perf_counter()
     if engine == "resident":
         ctx = capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"],
-                           parts["wall_vel"], lanes_per_particle=lanes_per_particle, steps_per_graph=steps_per_graph,
-                           rebuild_every=rebuild_every)
-        t, step = 0.0, 0
+                           parts["wall_vel"], t0=t_start, step0=step_start, lanes_per_particle=lanes_per_particle,
+                           steps_per_graph=steps_per_graph, rebuild_every=rebuild_every)
+        t, step = t_start, step_start
         try:
             while t < prm.t_end - 1e-12:
                 target = min(t + prm.output_interval, prm.t_end)
@@ -92,10 +109,12 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
                         log(f"step={step}, t={t:.6f}/{prm.t_end:.6f}, dt={st['dt_last']:.4e}, pairs={int(npairs)}, "
                             f"vmax={st['vmax']:.4f}\n  [thick-wall-noslip] tau_bot={tb:.4f}, tau_top={tt:.4f}, "
                             f"tau_target={prm.gravity_g * prm.rho0 * prm.DH / 2:.4f}")
-                d = ctx.download(fields=("pos", "vel"))
+                d = ctx.download() if restart_path else ctx.download(fields=("pos", "vel"))
                 _, u = compute_mid_channel_profile(d["pos"][:nf], d["vel"][:nf, 0], prm.DL, prm.DH, mid_x, mid_hw, n_bins)
                 profile_times.append(t)
                 mid_profiles.append(u)
+                if restart_path:
+                    restart.save_restart(restart_path, prm.config_signature, dict(d, t=t, step=step))
                 if log:
                     log(f"output point: t={t:.6f}, step={step}")
             wall = time.perf_counter() - t0
@@ -148,6 +167,9 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
     fluid_pos = pos[:nf].copy()
     fluid_pos[:, 0] = np.mod(fluid_pos[:, 0], prm.DL)
     y_mid, u_mean, u_exact = final_profile(fluid_pos, vel[:nf, 0], prm)
+    if postprocess_path:
+        restart.save_postprocess_data(postprocess_path, restart.make_postprocess_data(
+            prm, nf, pos, vel, n_bins, profile_times, np.column_stack([np.nan_to_num(u, nan=np.nan) for u in mid_profiles])))
     return RunResult(prm=prm, n_fluid=nf, n_total=nt, t=t, steps=int(step), wall_seconds=wall, pos=pos, vel=vel,
                      y_mid=y_mid, u_mean=u_mean, u_exact=u_exact, L2_error=l2_error(u_mean, u_exact),
                      profile_times=profile_times, mid_profile_u=mid_profiles, tau_bottom=tau_b, tau_top=tau_t,
