@@ -420,14 +420,16 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
     // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
-    const int e_row2 = t.nl_idx[2 * (size_t)t.nl_stride + tid], e_row3 = t.nl_idx[3 * (size_t)t.nl_stride + tid];
+    // (rows 2 and 3 only where lanes own that many: few lanes per particle)
+    const int e_row2 = LPP <= 8 ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
+    const int e_row3 = LPP <= 8 ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
     double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
     if (active) {
         const double xi = pi.x, yi = pi.y;
         for (int m = 0; m < nn_all; ++m) {
-            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (m == 2 ? e_row2 : (m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (LPP <= 8 && m == 2 ? e_row2 : (LPP <= 8 && m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
             const bool wall = (e & kWallBit) != 0;
             const int k = e & (kWallBit - 1);
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
@@ -474,7 +476,9 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
     // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
-    const int e_row2 = t.nl_idx[2 * (size_t)t.nl_stride + tid], e_row3 = t.nl_idx[3 * (size_t)t.nl_stride + tid];
+    // (rows 2 and 3 only where lanes own that many: few lanes per particle)
+    const int e_row2 = LPP <= 8 ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
+    const int e_row3 = LPP <= 8 ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     const bool tracked = s.posb != nullptr;
     const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
     const double dt = clk->dt;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     int first_wall = 1 << 20;  // wall neighbours are appended behind the fluid ones: this lane's rows >= first_wall
     if (active) {
         for (int m = 0; m < nn_all; ++m) {
-            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (m == 2 ? e_row2 : (m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (LPP <= 8 && m == 2 ? e_row2 : (LPP <= 8 && m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
             const int k = e & (kWallBit - 1);
             if (!(e & kWallBit)) {
                 const double2 pj = s.pos[k], vj = s.vel[k];
@@ -669,7 +673,9 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
     // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
-    const int e_row2 = t.nl_idx[2 * (size_t)t.nl_stride + tid], e_row3 = t.nl_idx[3 * (size_t)t.nl_stride + tid];
+    // (rows 2 and 3 only where lanes own that many: few lanes per particle)
+    const int e_row2 = LPP <= 8 ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
+    const int e_row3 = LPP <= 8 ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     const bool lead = in_cap && sub == 0;
     const double rhoh_i = lead ? t.a[i].z : 0.0;
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
     if (active) {
         for (int m = 0; m < nn_all; ++m) {
-            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (m == 2 ? e_row2 : (m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
+            const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (LPP <= 8 && m == 2 ? e_row2 : (LPP <= 8 && m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
             const bool wall = (e & kWallBit) != 0;
             const int k = e & (kWallBit - 1);
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
