@@ -58,6 +58,12 @@ class RingExchange:
         self.left, self.right = (rank - 1) % world, (rank + 1) % world
         backend = dist.get_backend(group)
         self.stage = (backend != "nccl") if stage_through_host is None else stage_through_host
+        # RCCL: the 8-byte max all-reduce gets a communicator (and therefore a stream) of its own, so it runs beside
+        # the halo messages instead of behind them -- both only wait for the pack kernel
+        self.reduce_group = None
+        if backend == "nccl" and world > 1 and os.environ.get("SPHX_SLAB_SERIAL_COLLECTIVES") != "1":
+            ranks = list(range(world)) if group is None else dist.get_process_group_ranks(group)
+            self.reduce_group = dist.new_group(ranks=ranks, backend="nccl")
 
     def __call__(self, send_l, send_r, recv_l, recv_r, vmax):
         dist = self.dist
@@ -71,6 +77,10 @@ class RingExchange:
             recv_l.copy_(hr_l)
             recv_r.copy_(hr_r)
             vmax.copy_(hv)
+        elif self.reduce_group is not None:
+            work = dist.all_reduce(vmax, op=dist.ReduceOp.MAX, group=self.reduce_group, async_op=True)
+            self._p2p(send_l, send_r, recv_l, recv_r)
+            work.wait()  # the current stream waits for the reduce stream; no host block
         else:
             self._p2p(send_l, send_r, recv_l, recv_r)
             dist.all_reduce(vmax, op=dist.ReduceOp.MAX, group=self.group)
