@@ -261,6 +261,16 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
     const int row_base = tid - sub;  // list column of lane 0 of this group
     // the LPP lanes of a particle test LPP consecutive candidates at a time (uniform trip count over the
     // group); accepted ones are packed with ballot + popcount
+    // a group (LPP <= 32 aligned lanes) lies in one 32-bit half of the wave's ballot: 32-bit shifts / popcounts
+    // (the candidate loop of the sweeping variants is VALU-bound)
+    const int half_shift = gbase & 31;
+    const unsigned grp_mask = LPP >= 32 ? 0xffffffffu : ((1u << (LPP & 31)) - 1u);
+    const unsigned below_me = (1u << sub) - 1u;  // sub <= 31
+    auto group_bits = [&](bool acc) -> unsigned {
+        const unsigned long long bal = __ballot(acc);
+        const unsigned half = lane < 32 ? (unsigned)bal : (unsigned)(bal >> 32);
+        return (half >> half_shift) & grp_mask;
+    };
     auto push = [&](bool acc, int entry) {
         if (LPP == 1) {
             if (acc) {
@@ -268,13 +278,12 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                 ++cnt;
             }
         } else {
-            const unsigned long long bal = __ballot(acc);
-            const unsigned long long grp = (bal >> gbase) & ((1ull << LPP) - 1ull);
+            const unsigned grp = group_bits(acc);
             if (acc) {
-                const int m = cnt + __popcll(grp & ((1ull << sub) - 1ull));
+                const int m = cnt + __popc(grp & below_me);
                 if (m / LPP < t.nl_cap) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
             }
-            cnt += __popcll(grp);
+            cnt += __popc(grp);
         }
     };
     auto push_super = [&](bool acc, int entry) {
@@ -284,13 +293,12 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                 ++scnt;
             }
         } else {
-            const unsigned long long bal = __ballot(acc);
-            const unsigned long long grp = (bal >> gbase) & ((1ull << LPP) - 1ull);
+            const unsigned grp = group_bits(acc);
             if (acc) {
-                const int m = scnt + __popcll(grp & ((1ull << sub) - 1ull));
+                const int m = scnt + __popc(grp & below_me);
                 if (m / LPP < t.sl_cap) t.sl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
             }
-            scnt += __popcll(grp);
+            scnt += __popc(grp);
         }
     };
     if (MODE == 2) {
