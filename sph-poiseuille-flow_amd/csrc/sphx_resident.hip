@@ -129,8 +129,8 @@ struct sphx_ctx {
     DevBuf<int> kid, counters, n_new;
     SlabPack pack{};
     int64_t slab_steps_enqueued = 0, slab_step0 = 0;
-    // each half-step is captured once per parity (and per buffer set) and replayed: 2 graph launches per step
-    // instead of ~14 kernel launches keep the host off the critical path of small slabs
+    // optional (SPHX_SLAB_GRAPH=1): each half-step captured once per parity (and per buffer set) and replayed;
+    // slower than plain launches for graphs this small, see slab_half
     hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
     const void *slab_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
@@ -1258,7 +1258,12 @@ namespace {
 template <typename Body>
 void slab_half(sphx_ctx *c, int half, int q, const void *const key[3], Body &&body)
 {
-    if (c->profiling) { body(); return; }
+    // Measured (one rank, 5 760 particles, exchange stubbed out): replaying a 6- and a 4-kernel graph per step costs
+    // 105 us/step of host time (hipGraphLaunch is ~50 us apiece on ROCm 7.2, the device waits); ten plain launches
+    // cost 36 us of host time and the step is device-bound at 70 us.  Graphs only pay when they hold many steps, as
+    // in the single-GPU loop; a slab half-step cannot (the exchange sits between the halves).
+    static const bool use_graph = std::getenv("SPHX_SLAB_GRAPH") != nullptr;
+    if (c->profiling || !use_graph) { body(); return; }
     hipGraphExec_t &exec = c->slab_graph[half][q];
     const bool same = exec && c->slab_key[half][0] == key[0] && c->slab_key[half][1] == key[1] && c->slab_key[half][2] == key[2];
     if (!same) {

@@ -187,7 +187,11 @@ class HipSlabEngine:
             self.capi.lib().sphx_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
 
 class SlabDriver:
