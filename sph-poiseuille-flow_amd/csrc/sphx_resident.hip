@@ -706,7 +706,9 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // Measured (MI355X, us/step, K=1 -> K=5): 4.8 k particles 47.5 -> 37.5 (launch-bound: 7 -> 5 launches per
     // step), 60 k 93.9 -> 80.2, 0.5 M 343 -> 316, 6 M 4101 -> 3907 (the wider cells lengthen the candidate sweeps
     // by ~10 %, the scatter/reorder kernels run on every fifth step only).
-    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : 5;
+    // With the superset list: K = 5 / 8 / 10 give 24.9 / 24.3 / 24.1 us/step at 5 k particles (fewer rebuild
+    // launches per step) but 2443 / 2490 / 2488 at 6 M (longer superset lists) -> 8 for small channels, 5 otherwise.
+    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 8 : 5);
     const double d_step = 0.035 * prm->h;
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
     if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
