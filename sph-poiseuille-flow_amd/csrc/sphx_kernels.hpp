@@ -99,7 +99,12 @@ struct FluidTmp {
     int sl_cap;
     double sl_rcut2;  // (2h + skin)^2
     int cap;         // particle capacity of every per-particle array (loads below it are always in bounds)
+    int n_vpart;     // entries of vpart / dpart (= workgroups of a pass)
+    double half_skin;  // < 0: drift not tracked
 };
+
+// "no value yet" in vpart when pass E carries the clock update in a tail workgroup (see continuity_tail)
+constexpr unsigned long long kVpartEmpty = ~0ull;
 
 struct Walls {
     const double2 *pos;
@@ -670,11 +675,67 @@ __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phy
 // dt (SPH_Poiseuille.m:521) and -- single-GPU -- the cell histogram of the end-of-step positions
 // (neighbour rebuild, the K0 insert of mex/sph_neighbor_search_mex.c:269-296).
 // ---------------------------------------------------------------------------------------------
-template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, Grid g, Phys ph,
-                                                       FluidSet s, FluidTmp t, Walls w, int do_hist)
+// Small channels: the clock update rides in pass E instead of being a launch of its own.  One extra workgroup
+// (the last one) waits for the per-block max |v|^2 of all the others, then advances the clock exactly as
+// k_clock_scan would.  Every vpart entry is its own "ready" flag: the producers store it with an agent-scope
+// atomic (past the non-coherent L2), the tail polls with agent-scope atomic loads and puts the "empty" pattern
+// back for the next step.  Nobody waits for the tail, so it cannot deadlock whatever the dispatch order; a grid
+// barrier (all wait for all) was measured at 70-90 us for 600 workgroups, this costs the tail ~1-2 us.
+__device__ __forceinline__ void continuity_tail(Clock *clk, int q, const Phys &ph, const FluidTmp &t, int nb)
 {
-    SPHX_PASS_INDEX();
+    if (!clk->run[q]) {
+        if (threadIdx.x == 0) clk->run[1 - q] = 0;  // idle slot keeps the following slots idle
+        return;
+    }
+    Clock c0;
+    int fl = 0;
+    if (threadIdx.x == 0) { c0 = *clk; fl = *t.flags; }
+    double m = 0.0, d = 0.0;
+    int lost = 0;
+    const bool track = t.half_skin >= 0.0;
+    for (int k = threadIdx.x; k < nb; k += kBlock) {
+        if (track) d = fmax(d, t.dpart[k]);  // written by pass CD, a kernel ago
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(&t.vpart[k]);
+        unsigned long long bits;
+        unsigned spins = 0;
+        while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kVpartEmpty) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) { lost = 1; break; }  // never hang the device on a protocol bug
+        }
+        if (!lost) m = fmax(m, __longlong_as_double((long long)bits));
+        __hip_atomic_store(slot, kVpartEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmax(m, __shfl_xor(m, off));
+        d = fmax(d, __shfl_xor(d, off));
+        lost |= __shfl_xor(lost, off);
+    }
+    __shared__ double s_m[kBlock / 64], s_d[kBlock / 64];
+    __shared__ int s_l[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; s_l[threadIdx.x >> 6] = lost; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); lost |= s_l[k]; }
+        if (lost) c0.status = SPHX_ERR_DIVERGED;
+        clock_step(clk, c0, q, ph, sqrt(m), fl, -1, track ? sqrt(d) : -1.0, 0, t.half_skin);
+    }
+}
+
+// tail: 1 = the launch has one workgroup more than the pass needs; it runs continuity_tail
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
+                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail)
+{
+    const int nb = (int)gridDim.x - tail;
+    if (tail && (int)blockIdx.x == nb) {
+        continuity_tail(clk, q, ph, t, nb);
+        return;
+    }
+    const int blk = xcd_block(blockIdx.x, nb);
+    const int tid = blk * kBlock + threadIdx.x;
+    const int i = tid / LPP, sub = tid % LPP;
+    const bool in_cap = i < t.cap;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? t.veln[i] : make_double2(0.0, 0.0);
     const int nn_all = t.nl_cnt[tid];
@@ -738,7 +799,11 @@ __global__ __launch_bounds__(kBlock) void k_continuity(const Clock *clk, int q, 
     if (threadIdx.x == 0) {
         double m = s_max[0];
         for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_max[k]);
-        t.vpart[blk] = m;
+        if (tail)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(&t.vpart[blk]), (unsigned long long)__double_as_longlong(m),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            t.vpart[blk] = m;
     }
 }
 
@@ -857,13 +922,13 @@ __global__ __launch_bounds__(kScanBlock) void k_max_tiles(const Clock *clk, int 
 //   vmax_global: slab mode -- the all-reduced max |v| replaces the local reduction.
 //   dpart / rebuilt / half_skin: displacement bookkeeping of grids that are rebuilt only every few steps.
 //   slab_counters: slab mode -- the keep/left/right counters of k_slab_pack, zeroed for the next step (the unpack
-//   kernel of this step has read them).
+//   kernel of this step has read them).  vpart_reset: see continuity_tail.
 __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Phys ph, int n_vpart,
                                                            const double *vpart, const double *vmax_global,
                                                            const int *flags, const int *count,
                                                            int *start_next, int n_scan, const int *n_new,
                                                            const double *dpart, int rebuilt, double half_skin,
-                                                           int *slab_counters)
+                                                           int *slab_counters, unsigned long long *vpart_reset)
 {
     // everything is requested before the run flag is looked at (stale values are harmless when the slot turns
     // out to be idle); only the thread that advances the clock loads it
@@ -896,6 +961,9 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
         clock_step(clk, c0, q, ph, vmax_global ? vg : sqrt(m), fl, nn, dpart ? sqrt(d) : -1.0, rebuilt, half_skin);
         if (slab_counters) { slab_counters[0] = 0; slab_counters[1] = 0; slab_counters[2] = 0; }  // pack counters of the next step
     }
+    // contexts whose move steps use the tail workgroup of pass E expect "empty" entries before every pass E
+    if (vpart_reset)
+        for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) vpart_reset[k] = kVpartEmpty;
     if (count) scan_counts(count, start_next, n_scan);
 }
 

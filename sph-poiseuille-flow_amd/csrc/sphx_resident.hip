@@ -134,12 +134,18 @@ struct sphx_ctx {
     hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
     const void *slab_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
+    bool tail_clock = false;     // move steps carry their clock update in a tail workgroup of pass E (small channels)
+
     FluidSet view(int q, int l)
     {
         return FluidSet{fpos_[q].get(), fvel_[q].get(), fdrho_[q].get(), fmass_[l].get(), fid_[l].get(),
                         fstart_[l].get(), fcell_[l].get(), skin > 0.0 ? fposb_[l].get() : nullptr};
     }
     double half_skin() const { return 0.5 * skin; }
+    unsigned long long *vpart_reset() const
+    {
+        return tail_clock ? reinterpret_cast<unsigned long long *>(vpart.get()) : nullptr;
+    }
 
     void drop_graph()
     {
@@ -214,8 +220,9 @@ ReorderArgs reorder_args(const double2 *pos, const double2 *vel, const double *d
 // only: 0 = all four, 1..4 = just density / kgc / forces / continuity (kernel timing)
 // dmode: 0 = pass A sweeps the cells; 1 = sweeps and writes the superset list (first step after a re-bin);
 //        2 = walks the superset list
+// tail: pass E gets one workgroup more, which advances the clock (no k_clock_scan after this step)
 template <int LPP>
-void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode)
+void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode, int tail)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
@@ -226,18 +233,21 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
     }
     if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
     if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
-    if (!only || only == 4) launch(c, "k_continuity", k_continuity<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, do_hist);
+    if (!only || only == 4)
+        launch(c, tail ? "k_continuity_clock" : "k_continuity", k_continuity<LPP>, dim3(c->n_blocks_particles + tail), bp,
+               c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
 }
 
-void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0, int dmode = 0)
+void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0, int dmode = 0,
+                        int tail = 0)
 {
     switch (c->lpp) {
-        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode); break;
-        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode); break;
-        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode); break;
-        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode); break;
-        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode); break;
-        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode); break;
+        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode, tail); break;
+        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode, tail); break;
+        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode, tail); break;
+        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode, tail); break;
+        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode, tail); break;
+        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode, tail); break;
         default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
     }
 }
@@ -295,11 +305,15 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         FluidTmp t = c->tmp;
         const FluidSet o = c->view(1 - q, l);
         t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+        if (c->tail_clock) {  // 4 launches: the last workgroup of pass E advances the clock
+            launch_physics_any(c, q, s, t, 0, 0, dmode, 1);
+            return;
+        }
         launch_physics_any(c, q, s, t, 0, 0, dmode);
         pre_reduce();
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(), (const int *)nullptr,
-               (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin(), (int *)nullptr);
+               (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin(), (int *)nullptr, c->vpart_reset());
         return;
     }
     launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
@@ -308,14 +322,14 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(),
-               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr);
+               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr, c->vpart_reset());
     } else {
         int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
         launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
                (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(), (const int *)tile_sum,
-               tile_off, c->n_tiles, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr);
+               tile_off, c->n_tiles, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr, c->vpart_reset());
         launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                (const int *)tile_off, c->grid.ncells, c->n_tiles);
     }
@@ -553,7 +567,10 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->fa.zero(c->stream); c->fB.zero(c->stream); c->drhon.zero(c->stream); c->rho_out.zero(c->stream); c->p_out.zero(c->stream);
     c->n_vpart = c->n_blocks_particles;
     c->vpart.alloc(c->n_vpart);
-    c->vpart.zero(c->stream);
+    // Small channels with a skin: move steps are 4 launches, the clock update rides in pass E (continuity_tail);
+    // vpart entries then double as "ready" flags and start out empty (all ones)
+    c->tail_clock = c->skin > 0.0 && !c->is_slab && c->n_vpart <= 2048 && !std::getenv("SPHX_NO_TAIL_CLOCK");
+    SPHX_HIP(hipMemsetAsync(c->vpart.get(), c->tail_clock ? 0xFF : 0, (size_t)c->n_vpart * sizeof(double), c->stream));
     c->dpart.alloc(c->n_vpart);
     c->dpart.zero(c->stream);
     c->n_vtiles = (!c->is_slab && c->n_vpart > 4 * kMaxTile) ? (int)div_up((size_t)c->n_vpart, kMaxTile) : 0;
@@ -580,7 +597,8 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->tmp = FluidTmp{c->posn.get(), c->veln.get(), c->drhon.get(), c->fa.get(), c->fB.get(), c->ffp.get(), c->ff.get(),
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
-                      (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap};
+                      (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
+                      c->skin > 0.0 ? c->half_skin() : -1.0};
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
@@ -1388,14 +1406,14 @@ SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const
         if (!c->big_scan) {
             launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
                    vmax_global_dev, (const int *)c->flags.get(), (const int *)c->count.get(), d.start, c->grid.ncells,
-                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get());
+                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get(), (unsigned long long *)nullptr);
         } else {
             int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
             launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
                    (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
             launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
                    vmax_global_dev, (const int *)c->flags.get(), (const int *)tile_sum, tile_off, c->n_tiles,
-                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get());
+                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get(), (unsigned long long *)nullptr);
             launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                    (const int *)tile_off, c->grid.ncells, c->n_tiles);
         }
@@ -1502,6 +1520,8 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         SPHX_HIP(hipEventRecord(a, c->stream));
         SPHX_HIP(hipGraphLaunch(e, c->stream));
         SPHX_HIP(hipEventRecord(b, c->stream));
+        if (c->tail_clock)  // the timed passes stored plain maxima: back to "empty" for the next real step
+            SPHX_HIP(hipMemsetAsync(c->vpart.get(), 0xFF, (size_t)c->n_vpart * sizeof(double), c->stream));
         SPHX_HIP(hipStreamSynchronize(c->stream));
         float ms = 0.f;
         SPHX_HIP(hipEventElapsedTime(&ms, a, b));
