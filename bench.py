@@ -39,6 +39,8 @@ BYTES_PER_WALL = {"k_density": 24, "k_kgc": 24, "k_forces": 48, "k_continuity": 
 for _k in ("_build", "_walk"):  # pass A sweeping cells + recording the superset list / walking the superset list
     BYTES_PER_FLUID["k_density" + _k] = BYTES_PER_FLUID["k_density"]
     BYTES_PER_WALL["k_density" + _k] = BYTES_PER_WALL["k_density"]
+BYTES_PER_FLUID["k_continuity_clock"] = BYTES_PER_FLUID["k_continuity"]  # pass E carrying the clock update
+BYTES_PER_WALL["k_continuity_clock"] = BYTES_PER_WALL["k_continuity"]
 STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
 
 
@@ -86,7 +88,7 @@ def pmc_traffic(name, kernel):
     2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of MI355X_MICROARCH.md applied); None if not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[name][kernel]["traffic_bytes"]
+            return json.load(f)[name][{"k_continuity_clock": "k_continuity"}.get(kernel, kernel)]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 

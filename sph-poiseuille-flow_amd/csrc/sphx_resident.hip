@@ -1494,7 +1494,7 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     if (n == "k_density" || n == "k_density_build" || n == "k_density_walk") only = 1;
     else if (n == "k_kgc") only = 2;
     else if (n == "k_forces") only = 3;
-    else if (n == "k_continuity") only = 4;
+    else if (n == "k_continuity" || n == "k_continuity_clock") only = 4;
     require(only != 0, "SPHX:Ctx:kernel", "time_kernel knows k_density, k_kgc, k_forces, k_continuity");
     read_clock(c);
     if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
