@@ -48,6 +48,20 @@ def test_headline_config_dp0025_20s(cfgmod, driver):
     assert abs(res.tau_bottom - res.tau_target) < 0.03
 
 
+@pytest.mark.parametrize("c_f, tc, ref_steps, ref_L2", [(15.0, 0.30, 24714, 0.0136), (10.0, 0.10, 16895, 0.0275)])
+def test_dp004_rows_of_the_reference_probe(cfgmod, driver, c_f, tc, ref_steps, ref_L2):
+    """BASELINE.md section 2, dp = 0.04: the shipped constants (24 714 steps, L2 1.36 %) and the README-table
+    constants c_f = 10, transport_coeff = 0.10 (16 895 steps, L2 2.75 %) -- a different sound speed (dt rule,
+    EOS stiffness) and shifting strength than every other run here.  The reference probe clipped dt only at
+    t_end; this driver also lands on every output point, so use one output interval."""
+    prm = cfgmod.params_from_values(dp=0.04, DL=3.0, c_f=c_f, transport_coeff=tc, end_time=20.0, output_interval=20.0)
+    res = driver.run(prm)
+    _record(f"dp0.04_cf{c_f:g}_tc{tc:g}", res)
+    assert abs(res.steps - ref_steps) <= 0.002 * ref_steps, (res.steps, ref_steps)   # dt sequence: vmax history
+    assert 0.5 * ref_L2 < res.L2_error < 1.6 * ref_L2, (res.L2_error, ref_L2)          # one chaotic realisation each
+    assert abs(res.tau_bottom - res.tau_target) < 0.04 and abs(res.tau_top - res.tau_target) < 0.04
+
+
 def test_mex_engine_matches_resident_engine(cfgmod, driver):
     """The unmodified six-calls-per-step loop through the MEX-surface mirror and the resident loop agree."""
     prm = cfgmod.params_from_values(dp=0.05, DL=1.5, end_time=0.02, output_interval=0.01)
