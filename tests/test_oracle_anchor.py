@@ -141,3 +141,24 @@ def test_sort_keeps_physics(cfgmod, geom, oracle):
         back = np.empty_like(b[k])
         back[inv] = b[k]
         assert_close(back, a[k], rtol=1e-9, atol_scale=1e-11, name=k)
+
+
+@pytest.mark.parametrize("kw, ref_steps, ref_L2", [
+    (dict(dp=0.05, DL=3.0), 19771, 0.0142),                                   # config.ini as shipped
+    (dict(dp=0.04, DL=3.0, c_f=10.0, transport_coeff=0.10), 16895, 0.0275),    # README-table constants
+])
+def test_full_runs_match_the_figures_recorded_from_the_reference(cfgmod, geom, oracle, profmod, kw, ref_steps, ref_L2):
+    """steps to t = 20 s and L2(20 s) of the reference's own C code (compiled unmodified
+    at survey time).  The step count is the sum of the dt sequence, i.e. of the whole max|v| history; the flow
+    is chaotic at round-off, so the L2 of one realisation is compared within a window.  Two parameter sets:
+    different sound speed (dt rule, EOS stiffness) and shifting strength."""
+    prm = cfgmod.params_from_values(end_time=20.0, output_interval=20.0, **kw)
+    parts = geom.init_particles(prm)
+    nf = parts["n_fluid"]
+    oracle.set_num_threads(8)
+    st = oracle.run(prm, parts, t_end=20.0, output_interval=20.0, enable_sort=False, omp=True)
+    assert abs(st["stats"]["steps"] - ref_steps) <= 0.002 * ref_steps, (st["stats"]["steps"], ref_steps)
+    y, um, ue = profmod.final_profile(st["pos"][:nf], st["vel"][:nf, 0], prm)
+    L2 = profmod.l2_error(um, ue)
+    assert 0.5 * ref_L2 < L2 < 1.7 * ref_L2, (L2, ref_L2)
+    assert abs(st["stats"]["tau_bottom"] - 0.4) < 0.04 and abs(st["stats"]["tau_top"] - 0.4) < 0.04
