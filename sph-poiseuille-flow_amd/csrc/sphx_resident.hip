@@ -110,7 +110,9 @@ struct sphx_ctx {
     int n_blocks_particles = 0;  // grid of the LPP kernels (capacity based)
     int n_blocks_flat = 0;       // grid of one-thread-per-particle kernels
 
-    hipGraphExec_t graph_exec[65] = {};  // one replayable graph per rebuild interval (index K), captured on demand
+    // replayable graphs per rebuild interval K and size: [K][0] holds the full spg-sized graph, [K][1] one period
+    // (2K slots) for short batches; captured on demand (the full one of the configured K at creation)
+    hipGraphExec_t graph_exec[65][2] = {};
     int64_t chunk_slots = 128;   // slots enqueued between two host looks at the clock (adaptive, see advance)
     bool profiling = false;
     KernelTimer timer;
@@ -149,10 +151,11 @@ struct sphx_ctx {
 
     void drop_graph()
     {
-        for (auto &e : graph_exec) {
-            if (e) (void)hipGraphExecDestroy(e);
-            e = nullptr;
-        }
+        for (auto &per_k : graph_exec)
+            for (auto &e : per_k) {
+                if (e) (void)hipGraphExecDestroy(e);
+                e = nullptr;
+            }
     }
 
     ~sphx_ctx()
@@ -368,10 +371,11 @@ int graph_slots(const sphx_ctx *c)
     return period * std::max(1, c->spg / period);
 }
 
-void build_graph(sphx_ctx *c)
+// which: 0 = the full graph (graph_slots), 1 = one period (2K slots)
+void build_graph(sphx_ctx *c, int which)
 {
-    const int K = c->rebuild_every, n = graph_slots(c);
-    if (c->graph_exec[K]) return;
+    const int K = c->rebuild_every, n = which ? 2 * K : graph_slots(c);
+    if (c->graph_exec[K][which]) return;
     const bool prof = c->profiling;
     c->profiling = false;
     SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -387,7 +391,7 @@ void build_graph(sphx_ctx *c)
     c->profiling = prof;
     hipGraph_t g = nullptr;
     SPHX_HIP(hipStreamEndCapture(c->stream, &g));
-    const hipError_t e = hipGraphInstantiate(&c->graph_exec[K], g, nullptr, nullptr, 0);
+    const hipError_t e = hipGraphInstantiate(&c->graph_exec[K][which], g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     SPHX_HIP(e);
 }
@@ -403,11 +407,14 @@ void enqueue_slots(sphx_ctx *c, int64_t slots)
         policy_before_slot(c);
         const int per_graph = graph_slots(c);
         const bool steady = c->rebuild_every == c->rebuild_every0 || c->prov_step + per_graph <= c->grow_at;
-        if (!c->profiling && steady && c->cur == 0 && c->lay == 0 && c->pos == 0 && left >= per_graph) {
-            build_graph(c);
-            SPHX_HIP(hipGraphLaunch(c->graph_exec[c->rebuild_every], c->stream));
-            left -= per_graph;  // back at (0,0,0); the last slot was a rebuild out of layout 1
-            c->prov_step += per_graph;
+        const int period = 2 * c->rebuild_every;
+        if (!c->profiling && steady && c->cur == 0 && c->lay == 0 && c->pos == 0 && left >= period) {
+            const int which = left >= per_graph ? 0 : 1;  // short batches: one period at a time
+            const int n = which ? period : per_graph;
+            build_graph(c, which);
+            SPHX_HIP(hipGraphLaunch(c->graph_exec[c->rebuild_every][which], c->stream));
+            left -= n;  // back at (0,0,0); the last slot was a rebuild out of layout 1
+            c->prov_step += n;
             c->out_lay = 1;
             continue;
         }
@@ -765,6 +772,12 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     upload_walls(c, nw, px + nf, py + nf, mass + nf, wall_vel + nf, wall_vel + ntz + nf, wid.data(), true);
     init_clock(c, nf, t0, step0);
     read_clock(c);
+    // capture the step graphs now, not inside somebody's timed region (a few ms) -- unless this context can never
+    // step (the one-shot contexts behind sphx_neighbor_search)
+    if (prm->t_end > t0) {
+        build_graph(c, 0);
+        if (graph_slots(c) != 2 * c->rebuild_every) build_graph(c, 1);
+    }
 }
 
 // emit the MEX-convention pair list of the current ordering into the ctx-held buffers
