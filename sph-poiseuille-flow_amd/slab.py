@@ -63,7 +63,7 @@ class RingExchange:
         self.reduce_group = None
         if backend == "nccl" and world > 1 and os.environ.get("SPHX_SLAB_SERIAL_COLLECTIVES") != "1":
             ranks = list(range(world)) if group is None else dist.get_process_group_ranks(group)
-            self.reduce_group = dist.new_group(ranks=ranks, backend="nccl")
+            self.reduce_group = dist.new_group(ranks=ranks, backend="nccl")  # collective call: every rank gets here
 
     def __call__(self, send_l, send_r, recv_l, recv_r, vmax):
         dist = self.dist
