@@ -209,8 +209,8 @@ __global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_st
     if (!(c.vmax == c.vmax) || isinf(c.vmax)) c.status = SPHX_ERR_DIVERGED;
     c.dt = next_dt(c, ph);
     const int go = loop_continues(c) ? 1 : 0;
-    c.run[q0] = go;
-    c.run[1 - q0] = 0;
+    c.run[0] = q0 == 0 ? go : 0;  // constant indices: a dynamically indexed member forces the struct into scratch
+    c.run[1] = q0 == 0 ? 0 : go;
     *clk = c;
 }
 
@@ -665,7 +665,9 @@ __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phy
     if (flags) c.status = SPHX_ERR_GRID;  // neighbour-list / slab-buffer overflow
     if (n_new >= 0) c.n = n_new;
     c.dt = next_dt(c, ph);
-    c.run[1 - q] = loop_continues(c) ? 1 : 0;
+    const int go = loop_continues(c) ? 1 : 0;
+    if (q == 0) c.run[1] = go;  // constant indices: c.run[1 - q] would force the whole struct into scratch memory --
+    else c.run[0] = go;         // 120 bytes per lane of EVERY wave of pass E when the tail workgroup lives there
     *clk = c;
 }
 
