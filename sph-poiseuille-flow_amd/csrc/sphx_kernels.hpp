@@ -101,6 +101,9 @@ struct FluidTmp {
     int cap;         // particle capacity of every per-particle array (loads below it are always in bounds)
     int n_vpart;     // entries of vpart / dpart (= workgroups of a pass)
     double half_skin;  // < 0: drift not tracked
+    double *vol;     // Vol once more, 8 bytes per particle: passes B and E gather nothing else of `a`, and pulling the
+                     // 32-byte records through the caches for one double costs them ~15 % (measured the other way
+                     // round: 64-byte records made them 25 % slower)
 };
 
 // "no value yet" in vpart when pass E carries the clock update in a tail workgroup (see continuity_tail)
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
         double rhoh = rho + 0.5 * dt * drho_i;
         if (rhoh < 1e-10) rhoh = ph.rho0;
         t.a[i] = make_double4(m / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho);
+        t.vol[i] = m / rho;
     }
 }
 
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
             const bool wall = (e & kWallBit) != 0;
             const int k = e & (kWallBit - 1);
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
-            const double Volj = (wall ? w.a : (const double4 *)t.a)[k].x;
+            const double Volj = wall ? w.a[k].x : t.vol[k];
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
@@ -761,15 +765,21 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
             const bool wall = (e & kWallBit) != 0;
             const int k = e & (kWallBit - 1);
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
-            const double4 aj = (wall ? w.a : (const double4 *)t.a)[k];  // .x = Vol either way; wall: .y,.z = wall velocity
             double2 vj;
-            if (wall) vj = make_double2(2.0 * aj.y - vxi, 2.0 * aj.z - vyi);  // mirrored wall velocity
-            else vj = t.veln[k];
+            double Volj;
+            if (wall) {
+                const double4 wj = w.a[k];  // {Vol, vx, vy, -}
+                Volj = wj.x;
+                vj = make_double2(2.0 * wj.y - vxi, 2.0 * wj.z - vyi);  // mirrored wall velocity
+            } else {
+                Volj = t.vol[k];
+                vj = t.veln[k];
+            }
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
             const double u_jump = (vxi - vj.x) * ex + (vyi - vj.y) * ey;
-            rate += u_jump * spline_dW(ph.kc, r) * aj.x;
+            rate += u_jump * spline_dW(ph.kc, r) * Volj;
         }
     }
     rate = group_sum<LPP>(rate);

@@ -95,7 +95,7 @@ struct sphx_ctx {
     DevBuf<int> fid_[2], fstart_[2], fcell_[2];
     DevBuf<double2> posn, veln, ffp, ff;
     DevBuf<double4> fa, fB;
-    DevBuf<double> drhon, rho_out, p_out, vpart, dpart, vtile;
+    DevBuf<double> drhon, rho_out, p_out, vpart, dpart, vtile, fvol;
     int n_vtiles = 0;            // > 0: k_max_tiles folds the per-block maxima first (very many blocks)
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, sl_idx, sl_cnt, flags, tile;
     DevBuf<double2> wpos;
@@ -569,7 +569,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
         if (c->skin > 0.0) c->fposb_[k].alloc(cap);
     }
     c->posn.alloc(cap); c->veln.alloc(cap); c->ffp.alloc(cap); c->ff.alloc(cap); c->fa.alloc(cap); c->fB.alloc(cap);
-    c->drhon.alloc(cap); c->rho_out.alloc(cap); c->p_out.alloc(cap);
+    c->drhon.alloc(cap); c->rho_out.alloc(cap); c->p_out.alloc(cap); c->fvol.alloc(cap); c->fvol.zero(c->stream);
     c->posn.zero(c->stream); c->veln.zero(c->stream); c->ffp.zero(c->stream); c->ff.zero(c->stream);
     c->fa.zero(c->stream); c->fB.zero(c->stream); c->drhon.zero(c->stream); c->rho_out.zero(c->stream); c->p_out.zero(c->stream);
     c->n_vpart = c->n_blocks_particles;
@@ -605,7 +605,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get()};
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
