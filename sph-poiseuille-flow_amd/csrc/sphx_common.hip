@@ -1,6 +1,10 @@
 // sphx_common.hip -- error state, device selection, version.
 #include "sphx_common.hpp"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace sphx {
 
 static thread_local std::string g_err_msg;
@@ -23,6 +27,83 @@ int report_unknown(const std::exception &e)
 {
     set_last_error(SPHX_ERR_DEVICE, "SPHX:Internal", e.what());
     return SPHX_ERR_DEVICE;
+}
+
+namespace {
+
+size_t pool_class(size_t bytes)
+{  // power of two below 1 MiB, whole MiB above: few distinct sizes, at most 2x slack on small blocks
+    size_t c = 256;
+    if (bytes <= (1u << 20)) {
+        while (c < bytes) c <<= 1;
+        return c;
+    }
+    return (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+}
+
+struct Pool {
+    std::mutex m;
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;  // (device, class) -> block
+    size_t cached = 0;
+    static constexpr size_t kMaxCached = (size_t)4 << 30;
+    void trim()
+    {
+        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+        cached = 0;
+    }
+    ~Pool() { /* process exit: the runtime reclaims device memory; HIP may already be torn down */ }
+};
+
+Pool &pool()
+{
+    static Pool *p = new Pool();  // never destroyed: DevBufs in static storage may outlive any static pool
+    return *p;
+}
+
+}  // namespace
+
+void *pool_alloc(size_t bytes)
+{
+    const size_t cls = pool_class(bytes);
+    int dev = 0;
+    SPHX_HIP(hipGetDevice(&dev));
+    Pool &P = pool();
+    {
+        std::lock_guard<std::mutex> lk(P.m);
+        auto it = P.free_blocks.find({dev, cls});
+        if (it != P.free_blocks.end()) {
+            void *p = it->second;
+            P.free_blocks.erase(it);
+            P.cached -= cls;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cls);
+    if (e != hipSuccess) {  // give the cache back and try once more
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(P.m);
+            P.trim();
+        }
+        e = hipMalloc(&p, cls);
+    }
+    SPHX_HIP(e);
+    return p;
+}
+
+void pool_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    const size_t cls = pool_class(bytes);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return; }
+    Pool &P = pool();
+    std::lock_guard<std::mutex> lk(P.m);
+    if (P.cached + cls > Pool::kMaxCached) { (void)hipFree(p); return; }
+    P.free_blocks.insert({{dev, cls}, p});
+    P.cached += cls;
 }
 
 void ensure_device()

@@ -160,6 +160,7 @@ struct sphx_ctx {
 
     ~sphx_ctx()
     {
+        if (stream) (void)hipStreamSynchronize(stream);  // the buffers go back to the pool: nothing may still use them
         drop_graph();
         for (auto &h : slab_graph) for (auto &e : h) if (e) (void)hipGraphExecDestroy(e);
         timer.collect();
@@ -1055,18 +1056,42 @@ SPHX_EXPORT int sphx_neighbor_search(const double *pos, int n_fluid, int n_total
         prm.rebuild_every = 1;
         const size_t nt = (size_t)n_total;
         std::vector<double> zeros2(2 * nt, 0.0), ones(nt, 1.0);
-        c = new sphx_ctx();
-        ctx_setup(c, &prm, n_fluid, n_total, pos, zeros2.data(), zeros2.data(), ones.data(), zeros2.data(), 0.0, 0);
+        // The driver calls this once per step with the same sizes (SPH_Poiseuille.m:428): keep the search context
+        // (stream, pinned clock, device arrays, wall grid shape) and only reload the positions.  Creating and
+        // destroying it every call cost 4.1 ms at 5 760 particles, the search itself 0.4 ms.
+        sphx_ctx *old = g_search_ctx;
+        bool reuse = false;
+        if (old && old->nf == n_fluid && old->nt == n_total && old->prm.h == h && old->prm.DL == DL) {
+            double y_min, y_max;
+            y_extent(pos + nt, n_total, y_min, y_max);
+            const double cs = 2.0 * h;
+            reuse = old->grid.y0 == y_min && old->grid.ncy == (int)std::ceil((y_max - y_min + 1e-12) / cs) + 1;
+        }
+        if (reuse) {
+            c = old;
+            const int nw = n_total - n_fluid;
+            upload_fluid(c, n_fluid, pos, pos + nt, zeros2.data(), zeros2.data(), zeros2.data(), ones.data(), nullptr, true);
+            std::vector<int> wid((size_t)std::max(nw, 1));
+            for (int k = 0; k < nw; ++k) wid[k] = n_fluid + k;
+            upload_walls(c, nw, pos + n_fluid, pos + nt + n_fluid, ones.data(), zeros2.data(), zeros2.data(), wid.data(), true);
+        } else {
+            c = new sphx_ctx();
+            ctx_setup(c, &prm, n_fluid, n_total, pos, zeros2.data(), zeros2.data(), ones.data(), zeros2.data(), 0.0, 0);
+        }
         emit_pairs(c, true);
         *n_pairs = c->pl_n;
-        if (g_search_ctx) delete g_search_ctx;
+        if (old && old != c) delete old;
         g_search_ctx = c;
         g_fetch_src = c;
         return SPHX_OK;
     } catch (const Error &e) {
+        if (c == g_search_ctx) g_search_ctx = nullptr;
+        if (g_fetch_src == c) g_fetch_src = nullptr;
         delete c;
         return report(e);
     } catch (const std::exception &e) {
+        if (c == g_search_ctx) g_search_ctx = nullptr;
+        if (g_fetch_src == c) g_fetch_src = nullptr;
         delete c;
         return report_unknown(e);
     }
@@ -1093,8 +1118,7 @@ SPHX_EXPORT int sphx_neighbor_fetch(double *pair_i, double *pair_j, double *dx, 
     }
     c->pl_valid = false;
     c->pl_i.release(); c->pl_j.release(); c->pl_dx.release(); c->pl_dy.release(); c->pl_r.release(); c->pl_W.release(); c->pl_dW.release();
-    g_fetch_src = nullptr;
-    if (g_search_ctx == c) { delete g_search_ctx; g_search_ctx = nullptr; }
+    g_fetch_src = nullptr;  // the search context itself stays for the next search of the same shape
     return SPHX_OK;
     SPHX_CATCH
 }
