@@ -214,6 +214,17 @@ def main():
                 out["aux"][aux_name] = {k: a[k] for k in ("value", "ms_per_step", "roofline", "kernels_ms", "workload", "tuning")}
             except Exception as e:  # never let the side measurements break the headline line
                 out["aux"][aux_name] = {"error": repr(e)}
+        # second half of the north-star metric: u(y) L2 vs the analytic parabola after the reference's full run
+        # (dp = 0.025, lattice at rest, t = 20 s, output every second) -- about a second of GPU time
+        try:
+            driver = importlib.import_module(PKG + ".driver")
+            full = driver.run(cfg.params_from_values(dp=0.025, DL=3.0, end_time=20.0, output_interval=1.0))
+            out["accuracy"] = {"config": "dp=0.025, DL=3, lattice at rest, t_end=20 s (BASELINE.md section 2: reference 39 496 steps, L2 0.84 %)",
+                               "L2": full.L2_error, "steps": full.steps, "wall_seconds": full.wall_seconds,
+                               "particle_steps_per_s": full.particle_steps_per_s,
+                               "wall_shear": [full.tau_bottom, full.tau_top], "wall_shear_target": full.tau_target}
+        except Exception as e:
+            out["accuracy"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, geo, prm, dict(parts, pos=pos, vel=vel), args.cpu_budget)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
