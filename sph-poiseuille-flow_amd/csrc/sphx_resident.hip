@@ -71,17 +71,16 @@ struct sphx_ctx {
     // particle was binned into, which finds all neighbours while nobody has drifted more than skin/2; the
     // device clock tracks the largest drift (Clock::drift) and stops the loop before the bound is violated.
     double skin = 0.0;
-    int rebuild_every = 1;       // interval in force; shrinks on back-to-back forced rebuilds, grows back to
-    int rebuild_every0 = 1;      // ... this configured value, one notch every kRegrowSteps steps
-    int64_t grow_at = 0;         // step index at which the interval takes its next notch back
+    int rebuild_every = 1;       // re-binning interval K (constant)
+    int64_t cool_until = 0;      // after a forced rebuild every step up to this step index re-bins (cool-down)
+    int64_t cool_len = 0;        // length of the last cool-down (doubles when forced rebuilds keep coming)
     int64_t prov_step = 0;       // step index the next enqueued slot will have if every slot before it executes
 
     // where the current state lives: state buffers S[cur] (x,y,vx,vy,drho), layout buffers L[lay]
     // (mass,id,start,cell); `pos` = steps taken since the grid was built.  Derived from the device step count.
     int cur = 0, lay = 0, pos = 0;
     int64_t epoch_step = 0;      // step count at which (epoch_cur, epoch_lay, epoch_pos, ...) held
-    int epoch_cur = 0, epoch_lay = 0, epoch_pos = 0, epoch_k = 1;
-    int64_t epoch_grow_at = 0;
+    int epoch_cur = 0, epoch_lay = 0, epoch_pos = 0;
     int epoch_out_lay = 0;
     int out_lay = 0;             // layout the per-step outputs (rho,p,force,Vol,B) are stored in; when it is not
                                  // `lay`, tmp.src_of maps current slots to the slots of those outputs
@@ -340,20 +339,15 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     launch_scatter_reorder(c, clk, q, reorder_args(c->tmp.posn, c->tmp.veln, c->tmp.drhon, s.mass, s.id, d, c->tmp.src_of), d);
 }
 
-constexpr int64_t kRegrowSteps = 1024;
-
-// The rebuild interval is part of the schedule, so it may only change at step indices that do not depend on
-// when the host happens to look: right after a forced rebuild (a device-side event) and at fixed distances
-// from the last change.  Called before every slot, both when enqueueing and when replaying.
-void policy_before_slot(sphx_ctx *c)
-{
-    if (c->rebuild_every < c->rebuild_every0 && c->prov_step >= c->grow_at) {
-        c->rebuild_every += 1;
-        c->grow_at = c->prov_step + kRegrowSteps;
-    }
-}
-
-bool slot_rebuilds(const sphx_ctx *c) { return c->pos >= c->rebuild_every - 1; }
+// A forced rebuild is answered with a COOL-DOWN: for the next cool_len steps every step re-bins (exactly the loop
+// without a skin), then the schedule returns to K.  What outruns the skin is almost always one particle making a
+// few large transport shifts in a row (max over millions of particles: at 0.5-6 M particles it happens every few
+// thousand steps); shrinking K for thousands of steps -- the first policy -- cost 30 % of the throughput of long
+// runs at those sizes.  The cool-down starts at 16 steps and doubles (up to 1024) while forced rebuilds keep coming
+// right after it ends, so a flow that really is too fast for the skin degrades to re-binning every step.
+// cool_until only changes at forced rebuilds (device-side events): the schedule stays independent of how the host
+// chunks its calls.
+bool slot_rebuilds(const sphx_ctx *c) { return c->pos >= c->rebuild_every - 1 || c->prov_step < c->cool_until; }
 
 // host-side bookkeeping of one executed step
 void track_step(sphx_ctx *c)
@@ -405,9 +399,8 @@ void enqueue_slots(sphx_ctx *c, int64_t slots)
 {
     int64_t left = slots;
     while (left > 0) {
-        policy_before_slot(c);
         const int per_graph = graph_slots(c);
-        const bool steady = c->rebuild_every == c->rebuild_every0 || c->prov_step + per_graph <= c->grow_at;
+        const bool steady = c->prov_step >= c->cool_until;
         const int period = 2 * c->rebuild_every;
         if (!c->profiling && steady && c->cur == 0 && c->lay == 0 && c->pos == 0 && left >= period) {
             const int which = left >= per_graph ? 0 : 1;  // short batches: one period at a time
@@ -430,7 +423,6 @@ void set_epoch(sphx_ctx *c)
 {
     c->epoch_step = c->h_clock->step;
     c->epoch_cur = c->cur; c->epoch_lay = c->lay; c->epoch_pos = c->pos; c->epoch_out_lay = c->out_lay;
-    c->epoch_k = c->rebuild_every; c->epoch_grow_at = c->grow_at;
     c->prov_step = c->epoch_step;
 }
 
@@ -442,12 +434,11 @@ void read_clock(sphx_ctx *c)
     // replay the bookkeeping of the steps that really executed since the last read
     const int64_t executed = (int64_t)c->h_clock->step - c->epoch_step;
     c->cur = c->epoch_cur; c->lay = c->epoch_lay; c->pos = c->epoch_pos; c->out_lay = c->epoch_out_lay;
-    c->rebuild_every = c->epoch_k; c->grow_at = c->epoch_grow_at; c->prov_step = c->epoch_step;
+    c->prov_step = c->epoch_step;
     if (executed > 0) {
         int64_t left = executed;
         while (left > 0) {
-            policy_before_slot(c);
-            if (c->rebuild_every == c->rebuild_every0 && left > 4 * c->rebuild_every) {
+            if (c->prov_step >= c->cool_until && left > 4 * c->rebuild_every) {
                 // steady interval: (cur, lay, pos) repeats every 2K steps -> skip whole periods
                 const int64_t period = 2 * c->rebuild_every, skip = ((left - 1) / period - 1) * period;
                 if (skip > 0) { c->prov_step += skip; left -= skip; }
@@ -489,15 +480,15 @@ void forced_rebuild(sphx_ctx *c)
     c->cur = 1 - q; c->lay = 1 - l; c->pos = 0;  // out_lay stays l
     c->h_clock->need_rebuild = 0;
     c->h_clock->drift = 0.0;
-    // Single particles now and then jump by a few tenths of h in one step (transport shift next to a void), which
-    // costs one host round trip here; only stops in back-to-back rebuild cycles mean the interval is too long.
+    // cool-down (see slot_rebuilds): 16 steps, doubled while the next forced rebuild follows the previous cool-down
+    // within two rebuild cycles
     const int64_t now = c->h_clock->step;
-    if (c->n_forced_rebuilds > 0 && now - c->last_forced_step <= 2 * (int64_t)c->rebuild_every && c->rebuild_every > 1)
-        c->rebuild_every -= 1;
-    c->grow_at = now + kRegrowSteps;
+    const bool again = c->n_forced_rebuilds > 0 && now - c->cool_until <= 2 * (int64_t)c->rebuild_every;
+    c->cool_len = again ? std::min<int64_t>(2 * std::max<int64_t>(c->cool_len, 16), 1024) : 16;
+    c->cool_until = now + c->cool_len;
     if (getenv("SPHX_DEBUG"))
-        fprintf(stderr, "sphx: forced rebuild #%lld at step %lld, drift bound hit; interval now %d (configured %d)\n",
-                (long long)c->n_forced_rebuilds + 1, (long long)now, c->rebuild_every, c->rebuild_every0);
+        fprintf(stderr, "sphx: forced rebuild #%lld at step %lld (drift bound hit): re-binning every step for %lld steps\n",
+                (long long)c->n_forced_rebuilds + 1, (long long)now, (long long)c->cool_len);
     c->last_forced_step = now;
     c->n_forced_rebuilds += 1;
     set_epoch(c);
@@ -739,7 +730,6 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
     if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
     c->rebuild_every = K;
-    c->rebuild_every0 = K;
     c->skin = skin;
 
     // grid: exact periodic tiling in x (cells >= 2h + skin), rows of 2h + skin in y over fluid + wall extent
