@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_FLUID = {"k_density": 40, "k_kgc": 56, "k_forces": 112 + 192, "k_continuity": 104,
                    "k_clock_scan": 0, "k_scatter": 8, "k_reorder": 16}
 BYTES_PER_WALL = {"k_density": 24, "k_kgc": 24, "k_forces": 48, "k_continuity": 24}
-for _k in ("_build", "_walk"):  # pass A sweeping cells + recording the superset list / walking the superset list
+for _k in ("_build", "_walk", "_dyn"):  # pass A sweeping cells + recording the superset list / walking the superset list
     BYTES_PER_FLUID["k_density" + _k] = BYTES_PER_FLUID["k_density"]
     BYTES_PER_WALL["k_density" + _k] = BYTES_PER_WALL["k_density"]
 BYTES_PER_FLUID["k_continuity_clock"] = BYTES_PER_FLUID["k_continuity"]  # pass E carrying the clock update
@@ -94,7 +94,7 @@ def pmc_traffic(name, kernel):
 
 
 def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=0, lattice=False,
-             rebuild_every=0, skin_h=0.0):
+             rebuild_every=0, skin_h=0.0, dynamic=0):
     """Time `steps` resident steps of one workload; returns (result dict, prm, parts, pos, vel)."""
     import torch
     prm = cfg.params_from_values(end_time=1e9, **kw)
@@ -107,7 +107,7 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
         start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
     ctx = capi.Context(prm, nf, nt, pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9,
                        lanes_per_particle=lpp, steps_per_graph=spg, rebuild_every=rebuild_every,
-                       skin_h=skin_h)
+                       skin_h=skin_h, dynamic_rebin=dynamic)
     info, tuning = ctx.info(), ctx.tuning()
     if warmup > 0:
         ctx.enqueue_steps(warmup)  # untimed: includes graph capture/instantiation
@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--spg", type=int, default=0, help="steps per hipGraph replay (0 = auto)")
     ap.add_argument("--rebuild-every", type=int, default=0, help="re-bin particles every K-th step (0 = auto)")
     ap.add_argument("--skin", type=float, default=0.0, help="cell skin in units of h (0 = sized from K)")
+    ap.add_argument("--dynamic", type=int, default=0, help="device-side re-bin decision: 0 = by size, 1 = on, 2 = off")
     ap.add_argument("--profile-steps", type=int, default=200, help="eager steps timed per kernel with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the C4/C5 side measurements of the default run")
@@ -190,7 +191,7 @@ def main():
 
     name, kw = parse_workload(args.workload or "C2")
     r, prm, parts, pos, vel = run_case(capi, cfg, geo, name, kw, args.steps, args.warmup, args.profile_steps, args.lpp,
-                                       args.spg, args.lattice, args.rebuild_every, args.skin)
+                                       args.spg, args.lattice, args.rebuild_every, args.skin, args.dynamic)
     value = r["value"]
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
@@ -208,9 +209,9 @@ def main():
         # the headline case is launch-latency bound (5 760 particles); report the same loop at 0.5 M and 6.1 M
         # particles as well so the kernels' throughput regime is on record (not the headline value)
         out["aux"] = {}
-        for aux_name, aux_steps in (("C4", 200), ("C5", 30)):
+        for aux_name, aux_steps in (("C4", 3000), ("C5", 600)):  # long enough to include re-binnings forced by the drift bound
             try:
-                a = run_case(capi, cfg, geo, aux_name, dict(WORKLOADS[aux_name]), aux_steps, 16, 16)[0]
+                a = run_case(capi, cfg, geo, aux_name, dict(WORKLOADS[aux_name]), aux_steps, 40, 16)[0]
                 out["aux"][aux_name] = {k: a[k] for k in ("value", "ms_per_step", "roofline", "kernels_ms", "workload", "tuning")}
                 out["aux"][aux_name]["window"] = (f"{aux_steps} steps right after a developed start; sustained figures of full "
                                                   "physical runs: DESIGN.md section 4 / profiles/r01_longrun_*.json")

@@ -149,7 +149,8 @@ typedef struct sphx_params {
                                    between, sweeps are centred on the cell a particle was binned into and
                                    the cells carry a skin (results do not depend on K beyond summation
                                    order: the device stops and re-bins before any neighbour can be missed) */
-    int32_t reserved2;
+    int32_t reserved2;          /* dynamic re-binning (the device decides when to re-bin, no host round trips): 0 = by
+                                   size (on from 10^6 fluid particles), 1 = on, 2 = off                             */
     double skin_h;              /* cell skin in units of h for K > 1; <= 0 = sized from K                  */
 } sphx_params;
 

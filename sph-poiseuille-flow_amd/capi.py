@@ -98,13 +98,13 @@ def set_device(dev: int) -> None:
 
 
 def make_params(prm, t_end=None, transport_coeff=None, lanes_per_particle=0, steps_per_graph=0, rebuild_every=0,
-                skin_h=0.0) -> SphxParams:
+                skin_h=0.0, dynamic_rebin=0) -> SphxParams:
     return SphxParams(DL=prm.DL, DH=prm.DH, dp=prm.dp, h=prm.h, rho0=prm.rho0, mu=prm.mu, c_f=prm.c_f,
                       p0=prm.p0, inv_sigma0=prm.inv_sigma0, gravity_g=prm.gravity_g,
                       transport_coeff=prm.transport_coeff if transport_coeff is None else transport_coeff,
                       t_end=prm.t_end if t_end is None else t_end, sort_interval=int(prm.sort_interval),
                       lanes_per_particle=int(lanes_per_particle), steps_per_graph=int(steps_per_graph),
-                      reserved=0, rebuild_every=int(rebuild_every), reserved2=0, skin_h=float(skin_h))
+                      reserved=0, rebuild_every=int(rebuild_every), reserved2=int(dynamic_rebin), skin_h=float(skin_h))
 
 
 class Context:
@@ -112,11 +112,11 @@ class Context:
 
     def __init__(self, prm, n_fluid, n_total, pos, vel, drho_dt, mass, wall_vel, t0=0.0, step0=0,
                  t_end=None, transport_coeff=None, lanes_per_particle=0, steps_per_graph=0, rebuild_every=0,
-                 skin_h=0.0):
+                 skin_h=0.0, dynamic_rebin=0):
         self._h = C.c_void_p()
         self.n_fluid, self.n_total = int(n_fluid), int(n_total)
         self.params = make_params(prm, t_end, transport_coeff, lanes_per_particle, steps_per_graph, rebuild_every,
-                                  skin_h)
+                                  skin_h, dynamic_rebin)
         pos, vel, wall_vel = f64(pos), f64(vel), f64(wall_vel)
         drho_dt, mass = f64(drho_dt), f64(mass)
         assert pos.shape == (n_total, 2) and vel.shape == (n_total, 2) and wall_vel.shape == (n_total, 2)

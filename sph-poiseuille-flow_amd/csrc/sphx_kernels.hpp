@@ -63,6 +63,13 @@ struct Clock {
     double drift;                // largest distance of any particle from where it was when the grid was built
     int need_rebuild;            // 1: drift exceeded half the cell skin -> the loop stopped, host must re-bin
     int pad;
+    // "dynamic" contexts (large channels): the device itself decides when to re-bin -- at the K-th step since the
+    // last re-binning or as soon as the drift exceeds skin/2 -- and the re-binning kernels of every step skip
+    // themselves unless rebuild_now is set; no host round trip, need_rebuild is never raised
+    int fresh;                   // 1: the grid has just been rebuilt (pass A sweeps the cells and records the superset list)
+    int rebuild_now;             // 1: the re-binning kernels of this step run
+    int pos_count;               // steps since the last re-binning
+    int n_drift_rebuilds;        // re-binnings triggered by the drift bound (statistics)
 };
 
 // Everything a neighbour pass GATHERS per neighbour is stored as 16- or 32-byte records (position, velocity,
@@ -200,6 +207,16 @@ __device__ __forceinline__ bool loop_continues(const Clock &c)
     return (c.t < c.t_target - 1e-12) && (c.steps_left != 0) && (c.status == 0) && (c.need_rebuild == 0);
 }
 
+// Kernels of the re-binning chain take the slot parity with a flag: bit 1 set = "only when the clock says
+// rebuild_now" (dynamic contexts), so the same kernels serve the scheduled and the device-decided re-binning.
+constexpr int kOnlyIfRebuild = 2, kOnlyIfNoHistogram = 4;
+__device__ __forceinline__ bool slot_active(const Clock *clk, int qf)
+{
+    if (!clk->run[qf & 1]) return false;
+    if ((qf & kOnlyIfNoHistogram) && clk->rebuild_now == 2) return false;  // pass E binned the particles already
+    return !(qf & kOnlyIfRebuild) || clk->rebuild_now != 0;
+}
+
 // one thread: arm the clock for an advance call.  vmax_in (optional) overrides the stored vmax (slab:
 // the all-reduced global value).
 __global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_steps, int q0,
@@ -243,10 +260,13 @@ constexpr int kWallBit = 1 << 30;
 // ---------------------------------------------------------------------------------------------
 // MODE 0: sweep the cells, write the step's list.  MODE 1: same sweep, also write the superset list.
 // MODE 2: walk the superset list instead of the cells.
+// cond_fresh (dynamic contexts launch both MODE 1 and MODE 2 on every step): -1 = always run, 1 = only on a fresh grid,
+// 0 = only on a grid that is not fresh.  (One kernel deciding at run time was 8 % slower than the two specialised ones.)
 template <int LPP, int MODE>
 __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Grid g, Phys ph,
-                                                    FluidSet s, FluidTmp t, Walls w)
+                                                    FluidSet s, FluidTmp t, Walls w, int cond_fresh)
 {
+    if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int ci = in_cap ? s.cell[i] : 0;
@@ -309,7 +329,9 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
             scnt += __popc(grp);
         }
     };
-    if (MODE == 2) {
+    constexpr bool walk = MODE == 2;
+    constexpr bool record = MODE == 1;  // also write the superset list
+    if (walk) {
         const int rows = LPP == 1 ? ns : __shfl(ns, gbase);  // lane 0 of the group owns the most rows
         if (active) {
             const double xi = pi.x, yi = pi.y;
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                 wide = r2 > kR2Min && r2 < t.sl_rcut2;
             }
             push(acc, k);
-            if (MODE == 1) push_super(wide, k);
+            if (record) push_super(wide, k);
         }
         if (near_wall) {
             const int w0 = whi[0] - wlo[0], w1 = whi[1] - wlo[1], w2 = whi[2] - wlo[2];
@@ -400,16 +422,16 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                     wide = r2 > kR2Min && r2 < t.sl_rcut2;
                 }
                 push(acc, k | kWallBit);
-                if (MODE == 1) push_super(wide, k | kWallBit);
+                if (record) push_super(wide, k | kWallBit);
             }
         }
         if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
-        if (MODE == 1 && scnt > t.sl_cap * LPP) { atomicOr(t.flags, 1); scnt = t.sl_cap * LPP; }
+        if (record && scnt > t.sl_cap * LPP) { atomicOr(t.flags, 1); scnt = t.sl_cap * LPP; }
     }
     // cnt is the particle's neighbour count (identical in all lanes of the group); lane `sub` owns entries
     // sub, sub+LPP, ...
     if (tid < t.nl_stride) t.nl_cnt[tid] = cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0;
-    if (MODE == 1 && tid < t.nl_stride) t.sl_cnt[tid] = scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0;
+    if (record && tid < t.nl_stride) t.sl_cnt[tid] = scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0;
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {
@@ -651,10 +673,21 @@ __device__ __forceinline__ int block_exclusive_scan_t(int v, int &total, int *s_
 
 // advance the device clock by the step that has just been computed (one thread)
 // drift: largest distance from the binning positions (< 0: not tracked); rebuilt: this step ends with a fresh grid.
+// dyn_K > 0: dynamic context -- decide here whether this step ends with a re-binning (K-th step, or drift bound hit)
 __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phys &ph, double vmax, int flags,
-                                           int n_new, double drift = -1.0, int rebuilt = 1, double half_skin = 0.0)
+                                           int n_new, double drift = -1.0, int rebuilt = 1, double half_skin = 0.0,
+                                           int dyn_K = 0)
 {
-    if (drift >= 0.0) {
+    if (dyn_K > 0) {
+        const bool by_drift = !(drift <= half_skin);
+        const bool sched = c.pos_count >= dyn_K - 1;  // pass E has taken the histogram already
+        const bool rb = by_drift || sched;
+        c.rebuild_now = rb ? (sched ? 2 : 1) : 0;     // 2: histogram done, k_bin skips
+        c.fresh = c.rebuild_now;  // the next pass A starts from a fresh grid
+        c.pos_count = rb ? 0 : c.pos_count + 1;
+        c.drift = rb ? 0.0 : drift;
+        if (by_drift) c.n_drift_rebuilds += 1;
+    } else if (drift >= 0.0) {
         c.drift = rebuilt ? 0.0 : drift;
         // every step sweeps the cells the particles were BINNED into; that finds all neighbours only while no
         // particle has drifted more than half the skin -> stop the loop, the host re-bins and resumes
@@ -753,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
     const int e_row3 = LPP <= 8 ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     const bool lead = in_cap && sub == 0;
     const double rhoh_i = lead ? t.a[i].z : 0.0;
-    const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);
+    const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
     const double dt = clk->dt;
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
@@ -795,7 +828,9 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
             v2 = vxi * vxi + vyi * vyi;
             if (v2 != v2) v2 = INFINITY;  // NaN poisons the max on purpose
         }
-        if (do_hist) {
+        // do_hist: 1 = this step re-bins (static schedule); 100 + K = dynamic context: the K-th step since the last
+        // re-binning will re-bin whatever the drift says, so its histogram can be taken here (k_bin then skips)
+        if (do_hist == 1 || (do_hist >= 100 && clk->pos_count >= do_hist - 101)) {
             int cx, cy;
             cell_of(g, pn.x, pn.y, cx, cy);
             const int c = cx * g.ncy + cy;
@@ -823,7 +858,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
 __global__ __launch_bounds__(kBlock) void k_bin(const Clock *clk, int q, Grid g, int n_fixed, const double2 *pos,
                                                 int *cellid, int *count)
 {
-    if (clk && !clk->run[q]) return;
+    if (clk && !slot_active(clk, q)) return;
     const int n = clk ? clk->n : n_fixed;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -885,7 +920,7 @@ __device__ __forceinline__ void scan_counts(const int *count, int *start, int n)
 __global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const Clock *clk, int q, const int *count, int *start,
                                                            int *tile_sum, int n)
 {
-    if (clk && !clk->run[q]) return;
+    if (clk && !slot_active(clk, q)) return;
     __shared__ int s_wave[kScanBlock / 64 + 1];
     const int idx = blockIdx.x * kScanBlock + (int)threadIdx.x;
     const int v = idx < n ? count[idx] : 0;
@@ -898,7 +933,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const Clock *clk, int
 __global__ __launch_bounds__(kScanBlock) void k_scan_add(const Clock *clk, int q, int *start, const int *tile_off,
                                                          int n, int n_tiles)
 {
-    if (clk && !clk->run[q]) return;
+    if (clk && !slot_active(clk, q)) return;
     const int idx = blockIdx.x * kScanBlock + (int)threadIdx.x;
     if (idx < n) start[idx] += tile_off[blockIdx.x];
     if (idx == 0) start[n] = tile_off[n_tiles];
@@ -940,7 +975,7 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
                                                            const int *flags, const int *count,
                                                            int *start_next, int n_scan, const int *n_new,
                                                            const double *dpart, int rebuilt, double half_skin,
-                                                           int *slab_counters, unsigned long long *vpart_reset)
+                                                           int *slab_counters, unsigned long long *vpart_reset, int dyn_K)
 {
     // everything is requested before the run flag is looked at (stale values are harmless when the slot turns
     // out to be idle); only the thread that advances the clock loads it
@@ -970,7 +1005,7 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
     if (threadIdx.x == 0) {
         for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
         // max of sqrt == sqrt of max (monotone, correctly rounded)
-        clock_step(clk, c0, q, ph, vmax_global ? vg : sqrt(m), fl, nn, dpart ? sqrt(d) : -1.0, rebuilt, half_skin);
+        clock_step(clk, c0, q, ph, vmax_global ? vg : sqrt(m), fl, nn, dpart ? sqrt(d) : -1.0, rebuilt, half_skin, dyn_K);
         if (slab_counters) { slab_counters[0] = 0; slab_counters[1] = 0; slab_counters[2] = 0; }  // pack counters of the next step
     }
     // contexts whose move steps use the tail workgroup of pass E expect "empty" entries before every pass E
@@ -981,7 +1016,7 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
 
 __global__ __launch_bounds__(kScanBlock) void k_scan_only(const Clock *clk, int q, const int *count, int *start, int n)
 {
-    if (clk && !clk->run[q]) return;
+    if (clk && !slot_active(clk, q)) return;
     scan_counts(count, start, n);
 }
 
@@ -990,7 +1025,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_only(const Clock *clk, int 
 __global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int n_fixed, const int *cellid,
                                                     int *count, const int *start_next, int *perm)
 {
-    if (clk && !clk->run[q]) return;
+    if (clk && !slot_active(clk, q)) return;
     const int n = clk ? clk->n : n_fixed;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -1019,7 +1054,7 @@ struct ReorderArgs {
 __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int n_fixed, const int *cellid,
                                                     const int *start_next, const int *perm, ReorderArgs a)
 {
-    if (clk && !clk->run[q]) return;
+    if (clk && !slot_active(clk, q)) return;
     const int n = clk ? clk->n : n_fixed;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -1224,11 +1259,41 @@ __global__ __launch_bounds__(kBlock) void k_pairs(const Clock *clk, Grid g, Phys
     if (!MODE) cnt[a] = n;
 }
 
-// scatter one component of a sorted field (records of `stride` doubles) back to the caller's row numbering
-__global__ __launch_bounds__(kBlock) void k_unsort(int n, const int *id, const double *src, int stride, double *dst)
+// scatter one component of a sorted field (records of `stride` doubles) back to the caller's row numbering;
+// src_of (optional): the field is stored in the ordering before the last re-binning, slot i was slot src_of[i] there
+__global__ __launch_bounds__(kBlock) void k_unsort(int n, const int *id, const double *src, int stride, double *dst,
+                                                   const int *src_of)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) dst[id[i]] = src[(size_t)i * stride];
+    if (i < n) dst[id[i]] = src[(size_t)(src_of ? src_of[i] : i) * stride];
+}
+
+// Dynamic contexts re-bin in place: k_reorder gathers into temporaries, this copies them back over the state of
+// the next step and the layout arrays (only on steps that re-bin).
+struct CopyBack {
+    const double2 *pos_s, *vel_s, *posb_s;
+    double2 *pos_d, *vel_d, *posb_d;
+    const double *drho_s, *mass_s;
+    double *drho_d, *mass_d;
+    const int *id_s, *cell_s, *start_s;
+    int *id_d, *cell_d, *start_d;
+    int n_start;  // ncells + 1
+};
+__global__ __launch_bounds__(kBlock) void k_copyback(const Clock *clk, int qf, CopyBack a)
+{
+    if (!slot_active(clk, qf)) return;
+    const int n = clk->n;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        a.pos_d[i] = a.pos_s[i];
+        a.vel_d[i] = a.vel_s[i];
+        a.posb_d[i] = a.posb_s[i];
+        a.drho_d[i] = a.drho_s[i];
+        a.mass_d[i] = a.mass_s[i];
+        a.id_d[i] = a.id_s[i];
+        a.cell_d[i] = a.cell_s[i];
+    }
+    if (i < a.n_start) a.start_d[i] = a.start_s[i];
 }
 
 __global__ __launch_bounds__(kBlock) void k_fill(int n, double *dst, double v)

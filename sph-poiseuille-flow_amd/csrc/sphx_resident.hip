@@ -135,6 +135,9 @@ struct sphx_ctx {
     hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
     const void *slab_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
+    // Dynamic re-binning (large channels): the device decides when to re-bin, every step carries the (self-skipping)
+    // re-binning kernels, the layout is rebuilt in place -> lay stays 0, only the state parity alternates
+    bool dyn = false;
     bool tail_clock = false;     // move steps carry their clock update in a tail workgroup of pass E (small channels)
 
     FluidSet view(int q, int l)
@@ -230,9 +233,13 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
     if (!only || only == 1) {
-        if (dmode == 0) launch(c, "k_density", k_density<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
-        else if (dmode == 1) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
-        else launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        if (dmode == 0) launch(c, "k_density", k_density<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
+        else if (dmode == 1) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
+        else if (dmode == 2) launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
+        else {  // dynamic: both, each skipping itself according to the clock's `fresh`
+            launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, 1);
+            launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, 0);
+        }
     }
     if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
     if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
@@ -316,7 +323,7 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         pre_reduce();
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(), (const int *)nullptr,
-               (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin(), (int *)nullptr, c->vpart_reset());
+               (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin(), (int *)nullptr, c->vpart_reset(), 0);
         return;
     }
     launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
@@ -325,14 +332,14 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(),
-               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr, c->vpart_reset());
+               (const int *)c->count.get(), d.start, c->grid.ncells, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr, c->vpart_reset(), 0);
     } else {
         int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
         launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
                (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
         launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red,
                vsrc, (const double *)nullptr, (const int *)c->flags.get(), (const int *)tile_sum,
-               tile_off, c->n_tiles, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr, c->vpart_reset());
+               tile_off, c->n_tiles, (const int *)nullptr, dpart, 1, c->half_skin(), (int *)nullptr, c->vpart_reset(), 0);
         launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                (const int *)tile_off, c->grid.ncells, c->n_tiles);
     }
@@ -349,9 +356,49 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
 // chunks its calls.
 bool slot_rebuilds(const sphx_ctx *c) { return c->pos >= c->rebuild_every - 1 || c->prov_step < c->cool_until; }
 
+// One step slot of a dynamic context: the four passes on S[q] writing the new state into S[1-q], the clock (which
+// decides rebuild_now), then the re-binning chain, every kernel of which returns at once unless rebuild_now is set:
+// histogram of the new positions, scan, scatter, id-canonical reorder into temporaries, copy back in place.
+void launch_step_dyn(sphx_ctx *c, int q)
+{
+    Clock *clk = c->clock.get();
+    const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
+    FluidTmp t = c->tmp;
+    t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+    launch_physics_any(c, q, s, t, 100 + c->rebuild_every, 0, 3);
+    const double *vsrc = c->vpart.get(), *dsrc = c->dpart.get();
+    int n_red = c->n_vpart;
+    if (c->n_vtiles) {
+        launch(c, "k_max_tiles", k_max_tiles, dim3(c->n_vtiles), dim3(kScanBlock), (const Clock *)clk, q, c->n_vpart,
+               (const double *)c->vpart.get(), (const double *)c->dpart.get(), c->vtile.get(), c->vtile.get() + c->n_vtiles);
+        vsrc = c->vtile.get(); dsrc = c->vtile.get() + c->n_vtiles; n_red = c->n_vtiles;
+    }
+    launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, n_red, vsrc, (const double *)nullptr,
+           (const int *)c->flags.get(), (const int *)nullptr, (int *)nullptr, 0, (const int *)nullptr, dsrc, 0, c->half_skin(),
+           (int *)nullptr, (unsigned long long *)nullptr, c->rebuild_every);
+    const int qf = q | kOnlyIfRebuild;
+    const dim3 g1(c->n_blocks_flat), bp(kBlock);
+    // temporaries of the in-place re-binning: the tmp state arrays and the (otherwise unused) second layout
+    const FluidSet d{c->posn.get(), c->veln.get(), c->drhon.get(), c->fmass_[1].get(), c->fid_[1].get(),
+                     c->fstart_[1].get(), c->fcell_[1].get(), c->fposb_[1].get()};
+    launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, qf | kOnlyIfNoHistogram, c->grid, 0, (const double2 *)o.pos,
+           c->cellid.get(), c->count.get());  // drift-triggered re-binnings only: pass E bins on the scheduled ones
+    launch_cell_scan(c, clk, qf, d.start);
+    launch_scatter_reorder(c, clk, qf, reorder_args(o.pos, o.vel, o.drho, s.mass, s.id, d, c->tmp.src_of), d);
+    CopyBack cb{d.pos, d.vel, d.posb, o.pos, o.vel, o.posb, d.drho, d.mass, o.drho, o.mass, d.id, d.cell, d.start,
+                o.id, o.cell, o.start, c->grid.ncells + 1};
+    launch(c, "k_copyback", k_copyback, dim3(std::max(c->n_blocks_flat, (int)div_up((size_t)c->grid.ncells + 1, kBlock))), bp,
+           (const Clock *)clk, qf, cb);
+}
+
 // host-side bookkeeping of one executed step
 void track_step(sphx_ctx *c)
 {
+    if (c->dyn) {
+        c->prov_step += 1;
+        c->cur ^= 1;
+        return;
+    }
     const bool rebuild = slot_rebuilds(c);
     c->prov_step += 1;
     c->out_lay = c->lay;  // outputs are stored in the layout the step ran in; after a rebuild tmp.src_of maps to it
@@ -362,20 +409,23 @@ void track_step(sphx_ctx *c)
 
 int graph_slots(const sphx_ctx *c)
 {
-    const int period = 2 * c->rebuild_every;  // (cur, lay, pos) returns to itself after 2K steps
+    const int period = c->dyn ? 2 : 2 * c->rebuild_every;  // (cur, lay, pos) returns to itself after 2K steps
     return period * std::max(1, c->spg / period);
 }
 
 // which: 0 = the full graph (graph_slots), 1 = one period (2K slots)
 void build_graph(sphx_ctx *c, int which)
 {
-    const int K = c->rebuild_every, n = which ? 2 * K : graph_slots(c);
+    const int K = c->rebuild_every, n = which ? (c->dyn ? 2 : 2 * K) : graph_slots(c);
     if (c->graph_exec[K][which]) return;
     const bool prof = c->profiling;
     c->profiling = false;
     SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     try {
-        for (int j = 0; j < n; ++j) launch_step(c, j & 1, (j / K) & 1, j % K, (j % K) == K - 1);
+        for (int j = 0; j < n; ++j) {
+            if (c->dyn) launch_step_dyn(c, j & 1);
+            else launch_step(c, j & 1, (j / K) & 1, j % K, (j % K) == K - 1);
+        }
     } catch (...) {
         hipGraph_t junk = nullptr;
         (void)hipStreamEndCapture(c->stream, &junk);
@@ -401,7 +451,7 @@ void enqueue_slots(sphx_ctx *c, int64_t slots)
     while (left > 0) {
         const int per_graph = graph_slots(c);
         const bool steady = c->prov_step >= c->cool_until;
-        const int period = 2 * c->rebuild_every;
+        const int period = c->dyn ? 2 : 2 * c->rebuild_every;
         if (!c->profiling && steady && c->cur == 0 && c->lay == 0 && c->pos == 0 && left >= period) {
             const int which = left >= per_graph ? 0 : 1;  // short batches: one period at a time
             const int n = which ? period : per_graph;
@@ -409,10 +459,11 @@ void enqueue_slots(sphx_ctx *c, int64_t slots)
             SPHX_HIP(hipGraphLaunch(c->graph_exec[c->rebuild_every][which], c->stream));
             left -= n;  // back at (0,0,0); the last slot was a rebuild out of layout 1
             c->prov_step += n;
-            c->out_lay = 1;
+            c->out_lay = c->dyn ? 0 : 1;
             continue;
         }
-        launch_step(c, c->cur, c->lay, c->pos, slot_rebuilds(c));
+        if (c->dyn) launch_step_dyn(c, c->cur);
+        else launch_step(c, c->cur, c->lay, c->pos, slot_rebuilds(c));
         track_step(c);
         --left;
     }
@@ -437,6 +488,10 @@ void read_clock(sphx_ctx *c)
     c->prov_step = c->epoch_step;
     if (executed > 0) {
         int64_t left = executed;
+        if (c->dyn) {  // only the parity matters
+            c->prov_step += left - (left & 1);
+            left &= 1;
+        }
         while (left > 0) {
             if (c->prov_step >= c->cool_until && left > 4 * c->rebuild_every) {
                 // steady interval: (cur, lay, pos) repeats every 2K steps -> skip whole periods
@@ -568,7 +623,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->vpart.alloc(c->n_vpart);
     // Small channels with a skin: move steps are 4 launches, the clock update rides in pass E (continuity_tail);
     // vpart entries then double as "ready" flags and start out empty (all ones)
-    c->tail_clock = c->skin > 0.0 && !c->is_slab && c->n_vpart <= 2048 && !std::getenv("SPHX_NO_TAIL_CLOCK");
+    c->tail_clock = c->skin > 0.0 && !c->is_slab && !c->dyn && c->n_vpart <= 2048 && !std::getenv("SPHX_NO_TAIL_CLOCK");
     SPHX_HIP(hipMemsetAsync(c->vpart.get(), c->tail_clock ? 0xFF : 0, (size_t)c->n_vpart * sizeof(double), c->stream));
     c->dpart.alloc(c->n_vpart);
     c->dpart.zero(c->stream);
@@ -665,6 +720,7 @@ void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
     k.t = t0; k.dt = 0.0; k.dt_last = 0.0; k.t_target = t0; k.t_end = c->prm.t_end; k.vmax = 0.0;
     k.step = step0; k.steps_left = -1; k.run[0] = 0; k.run[1] = 0; k.status = 0; k.n = n;
     k.drift = 0.0; k.need_rebuild = 0;
+    k.fresh = 1; k.rebuild_now = 0; k.pos_count = 0; k.n_drift_rebuilds = 0;
     *c->h_clock = k;
     SPHX_HIP(hipMemcpyAsync(c->clock.get(), c->h_clock, sizeof(Clock), hipMemcpyHostToDevice, s));
     SPHX_HIP(hipStreamSynchronize(s));
@@ -731,6 +787,10 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
     c->rebuild_every = K;
     c->skin = skin;
+    // Dynamic re-binning pays where a handful of empty launches per step is noise next to the passes (measured: the
+    // host-driven forced rebuilds + cool-downs cost 10-25 % of the sustained rate from 0.5 M particles up).
+    // reserved2: 0 = by size, 1 = on, 2 = off.
+    c->dyn = skin > 0.0 && (prm->reserved2 == 1 || (prm->reserved2 == 0 && nf >= 1000000));
 
     // grid: exact periodic tiling in x (cells >= 2h + skin), rows of 2h + skin in y over fluid + wall extent
     double y_min, y_max;
@@ -945,17 +1005,24 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
     const int nf = c->nf, nw = c->nw, nt = c->nt;
     hipStream_t s = c->stream;
     const FluidSet fs = c->view(c->cur, c->lay);
-    const int *id_old = c->fid_[c->out_lay].get();  // ordering the step outputs are stored in
+    // ordering the step outputs are stored in: the layout the step ran in (static schedule), or -- dynamic contexts,
+    // which re-bin in place -- the current ids reached through src_of when the last step ended with a re-binning
+    const int *id_old = c->dyn ? fs.id : c->fid_[c->out_lay].get();
+    const int *out_map = (c->dyn && c->h_clock->fresh) ? (const int *)c->src_of.get() : nullptr;
     DevBuf<double> stage((size_t)4 * nt);
     const dim3 gf(div_up(nf, kBlock)), gw(div_up(std::max(nw, 1), kBlock)), b(kBlock);
     auto col = [&](int cidx) { return stage.get() + (size_t)cidx * nt; };
     // component `comp` of a field stored as records of `stride` doubles
-    auto unsort_f = [&](const int *id, const void *src, int stride, int comp, int cidx) {
-        hipLaunchKernelGGL(k_unsort, gf, b, 0, s, nf, id, (const double *)src + comp, stride, col(cidx));
+    auto unsort_f = [&](const int *id, const void *src, int stride, int comp, int cidx) {  // current state
+        hipLaunchKernelGGL(k_unsort, gf, b, 0, s, nf, id, (const double *)src + comp, stride, col(cidx), (const int *)nullptr);
+    };
+    auto unsort_o = [&](const void *src, int stride, int comp, int cidx) {  // outputs of the last step
+        hipLaunchKernelGGL(k_unsort, gf, b, 0, s, nf, id_old, (const double *)src + comp, stride, col(cidx), out_map);
     };
     auto unsort_w = [&](const void *src, int stride, int comp, int cidx) {
         if (nw > 0)
-            hipLaunchKernelGGL(k_unsort, gw, b, 0, s, nw, (const int *)c->wid.get(), (const double *)src + comp, stride, col(cidx));
+            hipLaunchKernelGGL(k_unsort, gw, b, 0, s, nw, (const int *)c->wid.get(), (const double *)src + comp, stride, col(cidx),
+                               (const int *)nullptr);
     };
     auto fill_w = [&](int cidx, double v) {
         if (nw > 0) hipLaunchKernelGGL(k_fill, gw, b, 0, s, nw, col(cidx) + nf, v);
@@ -971,13 +1038,13 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
     }
     if (vel) { unsort_f(fs.id, fs.vel, 2, 0, 0); unsort_f(fs.id, fs.vel, 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(vel, 2); }
     if (drho_dt) { unsort_f(fs.id, fs.drho, 1, 0, 0); fill_w(0, 0.0); out(drho_dt, 1); }
-    if (rho) { unsort_f(id_old, c->rho_out.get(), 1, 0, 0); fill_w(0, c->prm.rho0); out(rho, 1); }
-    if (p) { unsort_f(id_old, c->p_out.get(), 1, 0, 0); fill_w(0, 0.0); out(p, 1); }
-    if (force) { unsort_f(id_old, c->ff.get(), 2, 0, 0); unsort_f(id_old, c->ff.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force, 2); }
-    if (force_prior) { unsort_f(id_old, c->ffp.get(), 2, 0, 0); unsort_f(id_old, c->ffp.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force_prior, 2); }
-    if (Vol) { unsort_f(id_old, c->fa.get(), 4, 0, 0); unsort_w(c->wa.get(), 4, 0, 0); out(Vol, 1); }
+    if (rho) { unsort_o(c->rho_out.get(), 1, 0, 0); fill_w(0, c->prm.rho0); out(rho, 1); }
+    if (p) { unsort_o(c->p_out.get(), 1, 0, 0); fill_w(0, 0.0); out(p, 1); }
+    if (force) { unsort_o(c->ff.get(), 2, 0, 0); unsort_o(c->ff.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force, 2); }
+    if (force_prior) { unsort_o(c->ffp.get(), 2, 0, 0); unsort_o(c->ffp.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force_prior, 2); }
+    if (Vol) { unsort_o(c->fa.get(), 4, 0, 0); unsort_w(c->wa.get(), 4, 0, 0); out(Vol, 1); }
     if (B) {
-        for (int k = 0; k < 4; ++k) unsort_f(id_old, c->fB.get(), 4, k, k);
+        for (int k = 0; k < 4; ++k) unsort_o(c->fB.get(), 4, k, k);
         fill_w(0, 1.0); fill_w(1, 0.0); fill_w(2, 0.0); fill_w(3, 1.0);
         out(B, 4);
     }
@@ -1000,7 +1067,7 @@ SPHX_EXPORT int sphx_ctx_monitor(sphx_ctx *c, double *tau_bottom, double *tau_to
             throw Error(SPHX_ERR_STATE, "SPHX:Ctx:monitor", "wall shear needs Vol/B of a completed step");
         const int nblk = c->n_blocks_flat;
         hipLaunchKernelGGL(k_wall_shear, dim3(nblk), dim3(kBlock), 0, s, (const Clock *)c->clock.get(), c->grid, c->phys, fs,
-                           c->tmp, c->walls, c->out_lay != c->lay ? 1 : 0, c->tau_part.get());
+                           c->tmp, c->walls, (c->dyn ? c->h_clock->fresh != 0 : c->out_lay != c->lay) ? 1 : 0, c->tau_part.get());
         hipLaunchKernelGGL(k_tau_final, dim3(1), dim3(kScanBlock), 0, s, nblk, (const double *)c->tau_part.get(),
                            c->phys.DL, c->tau_out.get());
         double h[2];
@@ -1163,7 +1230,7 @@ SPHX_EXPORT int sphx_ctx_grid_policy(sphx_ctx *c, int *rebuild_every, double *sk
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     if (rebuild_every) *rebuild_every = c->rebuild_every;
     if (skin) *skin = c->skin;
-    if (forced_rebuilds) *forced_rebuilds = c->n_forced_rebuilds;
+    if (forced_rebuilds) *forced_rebuilds = c->dyn ? (int64_t)c->h_clock->n_drift_rebuilds : c->n_forced_rebuilds;
     if (drift) *drift = c->h_clock->drift;
     return SPHX_OK;
     SPHX_CATCH
@@ -1433,14 +1500,14 @@ SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const
         if (!c->big_scan) {
             launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
                    vmax_global_dev, (const int *)c->flags.get(), (const int *)c->count.get(), d.start, c->grid.ncells,
-                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get(), (unsigned long long *)nullptr);
+                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get(), (unsigned long long *)nullptr, 0);
         } else {
             int *tile_sum = c->tile.get(), *tile_off = c->tile.get() + c->n_tiles + 1;
             launch(c, "k_scan_tiles", k_scan_tiles, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q,
                    (const int *)c->count.get(), d.start, tile_sum, c->grid.ncells);
             launch(c, "k_clock_scan", k_clock_scan, dim3(1), dim3(kScanBlock), clk, q, c->phys, 0, (const double *)nullptr,
                    vmax_global_dev, (const int *)c->flags.get(), (const int *)tile_sum, tile_off, c->n_tiles,
-                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get(), (unsigned long long *)nullptr);
+                   (const int *)c->n_new.get(), (const double *)nullptr, 1, 0.0, c->counters.get(), (unsigned long long *)nullptr, 0);
             launch(c, "k_scan_add", k_scan_add, dim3(c->n_tiles), dim3(kScanBlock), (const Clock *)clk, q, d.start,
                    (const int *)tile_off, c->grid.ncells, c->n_tiles);
         }
@@ -1518,7 +1585,7 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     require(!c->is_slab, "SPHX:Ctx:slab", "not available on a slab context");
     const std::string n(name);
     int only = 0;
-    if (n == "k_density" || n == "k_density_build" || n == "k_density_walk") only = 1;
+    if (n == "k_density" || n == "k_density_build" || n == "k_density_walk" || n == "k_density_dyn") only = 1;
     else if (n == "k_kgc") only = 2;
     else if (n == "k_forces") only = 3;
     else if (n == "k_continuity" || n == "k_continuity_clock") only = 4;
@@ -1535,7 +1602,7 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end, (long long)1,
                            c->cur, (const double *)nullptr);
         const FluidSet fs = c->view(c->cur, c->lay);
-        const int dmode = c->skin > 0.0 ? (c->pos == 0 ? 1 : 2) : 0;
+        const int dmode = c->dyn ? 3 : (c->skin > 0.0 ? (c->pos == 0 ? 1 : 2) : 0);
         launch_physics_any(c, c->cur, fs, c->tmp, 0, 0, dmode);  // make every temporary the timed kernel reads valid
         SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, fs, c->tmp, 0, only, dmode);

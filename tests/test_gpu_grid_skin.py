@@ -154,3 +154,64 @@ def test_narrow_domain_falls_back_to_every_step(cfgmod, geom, capi):
         pol = ctx.grid_policy()
         assert pol["rebuild_every"] == 1 and pol["skin"] == 0.0
         assert ctx.advance(1e9, max_steps=3)["step"] == 3
+
+
+# ---- dynamic re-binning (the device decides when to re-bin; default from 10^6 particles, forced on here) -------------
+
+@pytest.mark.parametrize("kw", [dict(rebuild_every=5), dict(rebuild_every=8, skin_h=0.03), dict(rebuild_every=3)])
+@pytest.mark.parametrize("n_steps", [1, 4, 9, 17])
+def test_dynamic_rebinning_matches_oracle(case, capi, oracle, kw, n_steps):
+    """Same physics whatever triggers the re-binning: the K-th step, or -- skin far too thin -- the drift bound on
+    (nearly) every step, decided on the device without the host."""
+    prm, parts = case
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=n_steps, enable_sort=False)
+    with _ctx(capi, prm, parts, dynamic_rebin=1, lanes_per_particle=4, **kw) as ctx:
+        st = ctx.advance(1e9, max_steps=n_steps)
+        got = ctx.download()
+        tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
+        pol = ctx.grid_policy()
+    assert st["step"] == n_steps
+    _check(got, ref, f"dyn{kw}")
+    assert npairs == ref["stats"]["n_pairs_last"]
+    assert_close(np.array([tb, tt]), np.array([ref["stats"]["tau_bottom"], ref["stats"]["tau_top"]]), rtol=1e-8,
+                 atol_scale=1e-9, name="tau")
+    if kw.get("skin_h") and n_steps >= 4:
+        assert pol["forced_rebuilds"] >= 1  # drift-triggered re-binnings, counted on the device
+
+
+def test_dynamic_rebinning_is_chunk_invariant_and_repeatable(case, capi):
+    prm, parts = case
+    kw = dict(dynamic_rebin=1, rebuild_every=6, skin_h=0.06, steps_per_graph=4)
+    n = 61
+    outs = []
+    for pattern in ("one", "single", "batches", "one"):
+        with _ctx(capi, prm, parts, **kw) as c:
+            if pattern == "one":
+                c.advance(1e9, max_steps=n)
+            elif pattern == "single":
+                for _ in range(n):
+                    c.advance(1e9, max_steps=1)
+            else:
+                for chunk in (7, 30, 1, 23):
+                    c.enqueue_steps(chunk)
+                assert c.sync()["step"] == n
+            outs.append(c.download(fields=("pos", "vel", "drho_dt", "rho", "Vol", "B")))
+            assert c.grid_policy()["forced_rebuilds"] >= 1
+    for o in outs[1:]:
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], o[k]), k
+
+
+def test_dynamic_pair_list_and_outputs_right_after_a_rebinning(case, capi, oracle):
+    """Outputs of a step that ended with a re-binning are stored in the old ordering (reached through src_of)."""
+    prm, parts = case
+    for n_steps in (3, 4):  # K = 4: step 4 ends with a re-binning, step 3 does not
+        ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=n_steps, enable_sort=False)
+        with _ctx(capi, prm, parts, dynamic_rebin=1, rebuild_every=4) as ctx:
+            ctx.advance(1e9, max_steps=n_steps)
+            got = ctx.download()
+            nb = ctx.neighbor_list()
+        _check(got, ref, f"dyn@{n_steps}")
+        refnb = oracle.neighbor_search(got["pos"], parts["n_fluid"], parts["n_total"], prm.h, prm.DL)
+        a, b = canon_pairs(nb), canon_pairs(refnb)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
