@@ -260,13 +260,10 @@ constexpr int kWallBit = 1 << 30;
 // ---------------------------------------------------------------------------------------------
 // MODE 0: sweep the cells, write the step's list.  MODE 1: same sweep, also write the superset list.
 // MODE 2: walk the superset list instead of the cells.
-// cond_fresh (dynamic contexts launch both MODE 1 and MODE 2 on every step): -1 = always run, 1 = only on a fresh grid,
-// 0 = only on a grid that is not fresh.  (One kernel deciding at run time was 8 % slower than the two specialised ones.)
 template <int LPP, int MODE>
-__global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Grid g, Phys ph,
-                                                    FluidSet s, FluidTmp t, Walls w, int cond_fresh)
+__device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
+                                             const FluidTmp &t, const Walls &w)
 {
-    if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int ci = in_cap ? s.cell[i] : 0;
@@ -442,6 +439,18 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
         t.a[i] = make_double4(m / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho);
         t.vol[i] = m / rho;
     }
+}
+
+// cond_fresh (dynamic contexts launch both MODE 1 and MODE 2 on every step): -1 = always run, 1 = only on a fresh grid,
+// 0 = only on a grid that is not fresh.  Measured at 6 M particles, average pass A per step: two launches of which one
+// returns 786 us; one kernel holding both bodies 891 us (it runs at the register budget of the bigger one); one
+// body deciding per candidate at run time 795 us.
+template <int LPP, int MODE>
+__global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Grid g, Phys ph,
+                                                    FluidSet s, FluidTmp t, Walls w, int cond_fresh)
+{
+    if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
+    density_body<LPP, MODE>(clk, q, g, ph, s, t, w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -860,14 +869,16 @@ __global__ __launch_bounds__(kBlock) void k_bin(const Clock *clk, int q, Grid g,
 {
     if (clk && !slot_active(clk, q)) return;
     const int n = clk ? clk->n : n_fixed;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    int cx, cy;
-    const double2 p = pos[i];
-    cell_of(g, p.x, p.y, cx, cy);
-    const int c = cx * g.ncy + cy;
-    cellid[i] = c;
-    atomicAdd(&count[c], 1);
+    // grid-stride: dynamic contexts launch the re-binning kernels on every step with a small grid, so that the
+    // launches that skip cost next to nothing
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        int cx, cy;
+        const double2 p = pos[i];
+        cell_of(g, p.x, p.y, cx, cy);
+        const int c = cx * g.ncy + cy;
+        cellid[i] = c;
+        atomicAdd(&count[c], 1);
+    }
 }
 
 // block-wide exclusive scan of one int per thread (kScanBlock threads); returns the block total
@@ -1027,11 +1038,11 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int
 {
     if (clk && !slot_active(clk, q)) return;
     const int n = clk ? clk->n : n_fixed;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int c = cellid[i];
-    const int k = atomicSub(&count[c], 1) - 1;
-    perm[start_next[c] + k] = i;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int c = cellid[i];
+        const int k = atomicSub(&count[c], 1) - 1;
+        perm[start_next[c] + k] = i;
+    }
 }
 
 struct ReorderArgs {
@@ -1056,28 +1067,28 @@ __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int
 {
     if (clk && !slot_active(clk, q)) return;
     const int n = clk ? clk->n : n_fixed;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int c = cellid[i];
-    const int lo = start_next[c], hi = start_next[c + 1];
-    const int my_id = a.id_src[i];
-    int rank = 0;
-    for (int k = lo; k < hi; ++k) {
-        const int o = perm[k];
-        const int oid = a.id_src[o];
-        rank += (oid < my_id || (oid == my_id && o < i)) ? 1 : 0;  // tie (periodic images in a slab): by slot
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int c = cellid[i];
+        const int lo = start_next[c], hi = start_next[c + 1];
+        const int my_id = a.id_src[i];
+        int rank = 0;
+        for (int k = lo; k < hi; ++k) {
+            const int o = perm[k];
+            const int oid = a.id_src[o];
+            rank += (oid < my_id || (oid == my_id && o < i)) ? 1 : 0;  // tie (periodic images in a slab): by slot
+        }
+        const int dst = lo + rank;
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+            if (f < a.n2) a.dst2[f][dst] = a.src2[f][i];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+            if (f < a.n1) a.dst1[f][dst] = a.src1[f][i];
+        if (a.n4) a.dst4[0][dst] = a.src4[0][i];
+        a.id_dst[dst] = my_id;
+        if (a.src_of) a.src_of[dst] = i;
+        if (a.cell_dst) a.cell_dst[dst] = c;
     }
-    const int dst = lo + rank;
-#pragma unroll
-    for (int f = 0; f < 3; ++f)
-        if (f < a.n2) a.dst2[f][dst] = a.src2[f][i];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-        if (f < a.n1) a.dst1[f][dst] = a.src1[f][i];
-    if (a.n4) a.dst4[0][dst] = a.src4[0][i];
-    a.id_dst[dst] = my_id;
-    if (a.src_of) a.src_of[dst] = i;
-    if (a.cell_dst) a.cell_dst[dst] = c;
 }
 
 __global__ void k_rebinned(Clock *clk)
@@ -1283,17 +1294,18 @@ __global__ __launch_bounds__(kBlock) void k_copyback(const Clock *clk, int qf, C
 {
     if (!slot_active(clk, qf)) return;
     const int n = clk->n;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) {
-        a.pos_d[i] = a.pos_s[i];
-        a.vel_d[i] = a.vel_s[i];
-        a.posb_d[i] = a.posb_s[i];
-        a.drho_d[i] = a.drho_s[i];
-        a.mass_d[i] = a.mass_s[i];
-        a.id_d[i] = a.id_s[i];
-        a.cell_d[i] = a.cell_s[i];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < max(n, a.n_start); i += gridDim.x * kBlock) {
+        if (i < n) {
+            a.pos_d[i] = a.pos_s[i];
+            a.vel_d[i] = a.vel_s[i];
+            a.posb_d[i] = a.posb_s[i];
+            a.drho_d[i] = a.drho_s[i];
+            a.mass_d[i] = a.mass_s[i];
+            a.id_d[i] = a.id_s[i];
+            a.cell_d[i] = a.cell_s[i];
+        }
+        if (i < a.n_start) a.start_d[i] = a.start_s[i];
     }
-    if (i < a.n_start) a.start_d[i] = a.start_s[i];
 }
 
 __global__ __launch_bounds__(kBlock) void k_fill(int n, double *dst, double v)

@@ -279,9 +279,9 @@ void launch_cell_scan(sphx_ctx *c, const Clock *clk, int q, int *start_next)
 }
 
 // index -> cell slot, then the gather of the persistent fields into destination view d
-void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderArgs &ra, const FluidSet &d)
+void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderArgs &ra, const FluidSet &d, int max_blocks = 0)
 {
-    const dim3 g1(c->n_blocks_flat), bp(kBlock);
+    const dim3 g1(max_blocks > 0 ? std::min(c->n_blocks_flat, max_blocks) : c->n_blocks_flat), bp(kBlock);
     launch(c, "k_scatter", k_scatter, g1, bp, clk, q, 0, (const int *)c->cellid.get(), c->count.get(), (const int *)d.start,
            c->perm.get());
     launch(c, "k_reorder", k_reorder, g1, bp, clk, q, 0, (const int *)c->cellid.get(), (const int *)d.start,
@@ -377,18 +377,18 @@ void launch_step_dyn(sphx_ctx *c, int q)
            (const int *)c->flags.get(), (const int *)nullptr, (int *)nullptr, 0, (const int *)nullptr, dsrc, 0, c->half_skin(),
            (int *)nullptr, (unsigned long long *)nullptr, c->rebuild_every);
     const int qf = q | kOnlyIfRebuild;
-    const dim3 g1(c->n_blocks_flat), bp(kBlock);
+    const int kDynBlocks = 4096;  // grid-stride kernels: a launch that skips costs ~3 us instead of an empty 24k-block grid
+    const dim3 g1(std::min(c->n_blocks_flat, kDynBlocks)), bp(kBlock);
     // temporaries of the in-place re-binning: the tmp state arrays and the (otherwise unused) second layout
     const FluidSet d{c->posn.get(), c->veln.get(), c->drhon.get(), c->fmass_[1].get(), c->fid_[1].get(),
                      c->fstart_[1].get(), c->fcell_[1].get(), c->fposb_[1].get()};
     launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, qf | kOnlyIfNoHistogram, c->grid, 0, (const double2 *)o.pos,
            c->cellid.get(), c->count.get());  // drift-triggered re-binnings only: pass E bins on the scheduled ones
     launch_cell_scan(c, clk, qf, d.start);
-    launch_scatter_reorder(c, clk, qf, reorder_args(o.pos, o.vel, o.drho, s.mass, s.id, d, c->tmp.src_of), d);
+    launch_scatter_reorder(c, clk, qf, reorder_args(o.pos, o.vel, o.drho, s.mass, s.id, d, c->tmp.src_of), d, kDynBlocks);
     CopyBack cb{d.pos, d.vel, d.posb, o.pos, o.vel, o.posb, d.drho, d.mass, o.drho, o.mass, d.id, d.cell, d.start,
                 o.id, o.cell, o.start, c->grid.ncells + 1};
-    launch(c, "k_copyback", k_copyback, dim3(std::max(c->n_blocks_flat, (int)div_up((size_t)c->grid.ncells + 1, kBlock))), bp,
-           (const Clock *)clk, qf, cb);
+    launch(c, "k_copyback", k_copyback, g1, bp, (const Clock *)clk, qf, cb);
 }
 
 // host-side bookkeeping of one executed step
