@@ -2,11 +2,12 @@
 # PMC passes for the resident step (manual profiling helper, not a test).  Usage: profile_pmc.sh WORKLOAD LPP STEPS TAG
 # (LPP 0 = auto).  Fold the result into profiles/ with tools/pmc_to_traffic.py.
 # One rocprofv3 run per counter group (counters are never combined with sys/hip/hsa trace domains).
-WL=${1:-C5}; LPP=${2:-0}; STEPS=${3:-20}; TAG=${4:-r1}
+WL=${1:-C5}; LPP=${2:-0}; STEPS=${3:-20}; TAG=${4:-r1}; EXTRA=${5:-}   # EXTRA e.g. "--dynamic 2": static schedule, so that
+# per-launch averages are not diluted by the launches that skip themselves in a dynamic context
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/pmc_${TAG}_${WL}"
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --workload $WL --lpp $LPP --steps $STEPS --warmup 4 --no-cpu-baseline --no-aux --profile-steps 0"
+CMD="python3 $ROOT/bench.py --workload $WL --lpp $LPP --steps $STEPS --warmup 4 --no-cpu-baseline --no-aux --profile-steps 0 $EXTRA"
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" \
