@@ -29,7 +29,10 @@
 //   * at a few thousand particles a pass is a chain of dependent memory round trips: every pass requests
 //     its own-particle data, its list row count and its first list rows before it waits for the run flag;
 //   * dt, t, the step counter, the particle count and the stop test live in a device-side clock so
-//     steps can be captured into a hipGraph and replayed.
+//     steps can be captured into a hipGraph and replayed.  Small channels: the clock update of a non-re-binning
+//     step rides in a tail workgroup of pass E (continuity_tail).  Large channels ("dynamic" contexts): the clock
+//     kernel also decides when to re-bin and the re-binning kernels of every step skip themselves otherwise
+//     (slot_active, clock_step).
 #pragma once
 #include "sphx_device.hpp"
 
