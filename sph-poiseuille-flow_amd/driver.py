@@ -6,7 +6,7 @@ Two engines with the same observable behaviour:
     (:294-301) and for the every-20-steps log line (:285-291, opt-in).
   * engine="mex": the reference's own call sequence, six MEX-surface calls per step through
     mex_surface.py (:254-281) -- kept to show that the per-call surface is a drop-in.
-The restart file (:127-163,:295) and the plots (S7) are out of scope.
+Restart / post-process files (:127-163,:295,:305-306) go through restart.py; the plots (S7) are out of scope.
 """
 from __future__ import annotations
 
@@ -42,6 +42,13 @@ class RunResult:
     tau_top: float = 0.0
     tau_target: float = 0.0
     grid_policy: dict = field(default_factory=dict)  # resident engine: rebuild interval, skin, forced rebuilds
+    full_profile_u: list = field(default_factory=list)  # whole-channel binned u_x(y) at every output point
+
+    def L2_time_mean(self, last=5):
+        """L2 of the whole-channel profile averaged over the last `last` output points: the instantaneous profile of
+        one chaotic realisation wanders by ~0.1 pp around its mean, the average does not."""
+        u = np.nanmean(np.stack(self.full_profile_u[-last:]), axis=0)
+        return l2_error(u, self.u_exact)
 
     @property
     def particle_steps_per_s(self):
@@ -87,7 +94,7 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
             log(f"Restart file not used ({why}); starting from scratch")
     n_bins = n_profile_bins(prm.DH, prm.dp)
     mid_x, mid_hw = 0.5 * prm.DL, max(prm.dp, prm.h)
-    profile_times, mid_profiles = [0.0], []
+    profile_times, mid_profiles, full_profiles = [0.0], [], []
     _, u0 = compute_mid_channel_profile(parts["pos"][:nf], parts["vel"][:nf, 0], prm.DL, prm.DH, mid_x, mid_hw, n_bins)
     mid_profiles.append(u0)
     tau_b = tau_t = 0.0
@@ -113,6 +120,8 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
                 _, u = compute_mid_channel_profile(d["pos"][:nf], d["vel"][:nf, 0], prm.DL, prm.DH, mid_x, mid_hw, n_bins)
                 profile_times.append(t)
                 mid_profiles.append(u)
+                full_profiles.append(final_profile(np.column_stack([np.mod(d["pos"][:nf, 0], prm.DL), d["pos"][:nf, 1]]),
+                                                   d["vel"][:nf, 0], prm)[1])
                 if restart_path:
                     restart.save_restart(restart_path, prm.config_signature, dict(d, t=t, step=step))
                 if log:
@@ -160,6 +169,7 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
             _, u = compute_mid_channel_profile(S["pos"][:nf], S["vel"][:nf, 0], prm.DL, prm.DH, mid_x, mid_hw, n_bins)
             profile_times.append(t)
             mid_profiles.append(u)
+            full_profiles.append(final_profile(S["pos"][:nf], S["vel"][:nf, 0], prm)[1])
         wall = time.perf_counter() - t0
         pos, vel = S["pos"], S["vel"]
     else:
@@ -173,4 +183,4 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
     return RunResult(prm=prm, n_fluid=nf, n_total=nt, t=t, steps=int(step), wall_seconds=wall, pos=pos, vel=vel,
                      y_mid=y_mid, u_mean=u_mean, u_exact=u_exact, L2_error=l2_error(u_mean, u_exact),
                      profile_times=profile_times, mid_profile_u=mid_profiles, tau_bottom=tau_b, tau_top=tau_t,
-                     tau_target=prm.gravity_g * prm.rho0 * prm.DH / 2, grid_policy=policy)
+                     tau_target=prm.gravity_g * prm.rho0 * prm.DH / 2, grid_policy=policy, full_profile_u=full_profiles)

@@ -1,0 +1,89 @@
+"""-m gpu: BASELINE.json configs[2..4] (C3 dp 0.01/DL 6, C4 dp 0.005/DL 12, C5 dp 0.002/DL 24) on the DEFAULT
+context against the oracle's time loop -- the code paths the small cases never reach: automatic lanes per
+particle (4), the multi-block cell scan (> 8 192 cells: k_scan_tiles / k_scan_add), k_max_tiles (> 16 k
+workgroups), the grid-stride re-binning kernels, size_t index products and, from 10^6 fluid particles, the
+device-decided ("dynamic") re-binning with its in-place reorder (k_copyback).
+
+Every case runs past the first scheduled re-binning (K = 5 above 20 k particles), so the list rebuilt from the
+re-binned layout is compared as well.  All nine step outputs, the dt sequence (through t), max|v|, the pair
+count of the rebuilt neighbour structure and the wall shear are compared particle by particle at the same
+tolerance as the small cases (rtol 1e-9 after <= 10 steps; reference loop: SPH_Poiseuille.m:250-292,
+neighbor.c:312-392, physics.c:857-957).  The oracle is serial C: ~2 us per particle-step (C5: ~70 s).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_close, make_case
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
+#        name   dp     DL    steps  expected policy
+CASES = [("C3", 0.01, 6.0, 7, dict(lpp=4, dynamic=False, big_scan=False)),
+         ("C4", 0.005, 12.0, 6, dict(lpp=4, dynamic=False, big_scan=True)),
+         ("C5", 0.002, 24.0, 6, dict(lpp=4, dynamic=True, big_scan=True))]
+
+
+def _compare(name, prm, parts, n_steps, capi, oracle, expect, **ctx_kw):
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
+                      t_end=1e9, **ctx_kw) as ctx:
+        info, tun, pol = ctx.info(), ctx.tuning(), ctx.grid_policy()
+        st = ctx.advance(1e9, max_steps=n_steps)
+        got = ctx.download()
+        tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
+        pol_after = ctx.grid_policy()
+    # the launch shape / grid policy this configuration is supposed to exercise
+    if "lpp" in expect:
+        assert tun["lanes_per_particle"] == expect["lpp"], tun
+    if "big_scan" in expect:
+        assert (info["n_cell_x"] * info["n_cell_y"] > 8192) == expect["big_scan"], info
+    assert pol["rebuild_every"] < n_steps, (pol, n_steps)  # the run re-bins at least once
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=n_steps, enable_sort=False)
+    assert st["step"] == n_steps == ref["stats"]["steps"]
+    assert abs(st["t"] - ref["stats"]["t"]) <= 1e-13 * ref["stats"]["t"]
+    assert abs(st["dt_last"] - ref["stats"]["dt_last"]) <= 1e-12 * ref["stats"]["dt_last"]
+    assert abs(st["vmax"] - ref["stats"]["vmax"]) <= 1e-9 * ref["stats"]["vmax"]
+    for k in FIELDS:
+        assert_close(got[k], ref[k], rtol=1e-9, atol_scale=1e-10, name=f"{name}:{k}@{n_steps}")
+    assert npairs == ref["stats"]["n_pairs_last"], (npairs, ref["stats"]["n_pairs_last"])
+    assert_close(np.array([tb, tt]), np.array([ref["stats"]["tau_bottom"], ref["stats"]["tau_top"]]), rtol=1e-8,
+                 atol_scale=1e-9, name=f"{name}:tau")
+    assert np.all(got["pos"][:nf, 0] >= 0) and np.all(got["pos"][:nf, 0] <= prm.DL)
+    return pol_after
+
+
+@pytest.mark.parametrize("name,dp,DL,n_steps,expect", CASES, ids=[c[0] for c in CASES])
+def test_default_context_matches_oracle(name, dp, DL, n_steps, expect, cfgmod, geom, capi, oracle):
+    prm, parts = make_case(cfgmod, geom, dp=dp, DL=DL, jitter=0.2, seed=11, developed=True)
+    _compare(name, prm, parts, n_steps, capi, oracle, expect)
+
+
+def test_c4_dynamic_rebinning_matches_oracle(cfgmod, geom, capi, oracle):
+    """0.5 M particles with the device-decided re-binning forced on and a skin small enough that the drift bound
+    (not the schedule) triggers re-binnings inside the window: k_bin + the multi-block scan + k_copyback."""
+    prm, parts = make_case(cfgmod, geom, dp=0.005, DL=12.0, jitter=0.2, seed=5, developed=True)
+    pol = _compare("C4dyn", prm, parts, 6, capi, oracle, dict(lpp=4, big_scan=True), dynamic_rebin=1, skin_h=0.05)
+    assert pol["forced_rebuilds"] >= 1, pol  # re-binnings triggered by the drift bound
+
+
+def test_c3_lattice_start_matches_oracle(cfgmod, geom, capi, oracle):
+    """The reference's own initial state (pristine lattice at rest): sums that cancel exactly on the lattice are
+    compared with absolute floors (helpers.assert_close's atol_scale on the field's magnitude)."""
+    prm = cfgmod.params_from_values(dp=0.01, DL=6.0)
+    parts = geom.init_particles(prm)
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    assert (nf, nt) == (60000, 64800)
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=3, enable_sort=False)
+    with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
+                      t_end=1e9) as ctx:
+        st = ctx.advance(1e9, max_steps=3)
+        got = ctx.download()
+        _, _, npairs = ctx.monitor(tau=False, pairs=True)
+    assert st["step"] == 3 and abs(st["t"] - ref["stats"]["t"]) <= 1e-13 * ref["stats"]["t"]
+    assert npairs == ref["stats"]["n_pairs_last"] == 606600  # recorded from the reference
+    for k in ("pos", "vel", "rho", "Vol", "B"):
+        assert_close(got[k], ref[k], rtol=1e-9, atol_scale=1e-10, name=f"C3lattice:{k}")
+    scale = prm.p0 * prm.dp  # force scale of a pressure difference of p0 over one spacing, per unit volume
+    for k in ("p", "drho_dt", "force", "force_prior"):
+        assert_close(got[k], ref[k], rtol=1e-9, atol_scale=1e-10, atol=1e-9 * scale, name=f"C3lattice:{k}")

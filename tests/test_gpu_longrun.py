@@ -19,6 +19,7 @@ def _record(name, res):
         os.makedirs(OUT, exist_ok=True)
         with open(os.path.join(OUT, f"longrun_{name}.json"), "w") as f:
             json.dump(dict(n_total=res.n_total, steps=res.steps, t=res.t, wall_seconds=res.wall_seconds, L2=res.L2_error,
+                           L2_mean_last5=res.L2_time_mean(5) if len(res.full_profile_u) >= 5 else None,
                            particle_steps_per_s=res.particle_steps_per_s, tau_bottom=res.tau_bottom, tau_top=res.tau_top,
                            tau_target=res.tau_target, u_mean=np.nan_to_num(res.u_mean).tolist(), u_exact=res.u_exact.tolist()), f)
     except OSError:
@@ -44,7 +45,10 @@ def test_headline_config_dp0025_20s(cfgmod, driver):
     res = driver.run(prm)
     _record("dp0.025", res)
     assert 39300 <= res.steps <= 39800, res.steps           # reference 39 496
-    assert res.L2_error < 0.0125, res.L2_error              # realisation spread around the reference's 0.84 %
+    # the north-star bar: L2 <= 1 % at t = 20 s, and -- the same bar on a statistic that does not ride on one chaotic
+    # realisation -- on the profile averaged over the output points t = 16..20 s
+    assert res.L2_error <= 0.01, res.L2_error
+    assert res.L2_time_mean(last=5) <= 0.01, res.L2_time_mean(last=5)
     assert abs(res.tau_bottom - res.tau_target) < 0.03
 
 

@@ -42,3 +42,13 @@ def test_slab_hip_two_ranks_one_gpu(lpp):
     r = _launch(2, "--engine", "hip", "--steps", "7", "--dp", "0.05", "--DL", "3.0", "--lpp", str(lpp), port=29531 + lpp)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_slab_hip_two_ranks_half_million_particles():
+    """C4 (dp 0.005, DL 12: 499 200 particles) cut into two slabs sharing the GPU: the multi-block cell scan
+    (> 8 192 cells per slab window), automatic lanes per particle and message buffers of thousands of
+    particles -- against the single-GPU context, which test_gpu_large_configs.py pins to the oracle."""
+    r = _launch(2, "--engine", "hip", "--steps", "4", "--dp", "0.005", "--DL", "12.0", port=29541)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "OK" in r.stdout
