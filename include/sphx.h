@@ -149,8 +149,8 @@ typedef struct sphx_params {
                                    between, sweeps are centred on the cell a particle was binned into and
                                    the cells carry a skin (results do not depend on K beyond summation
                                    order: the device stops and re-bins before any neighbour can be missed) */
-    int32_t reserved2;          /* dynamic re-binning (the device decides when to re-bin, no host round trips): 0 = by
-                                   size (on from 10^6 fluid particles), 1 = on, 2 = off                             */
+    int32_t dynamic_rebin;      /* device-decided re-binning (no host round trips): 0 = by size (on from 10^6 fluid
+                                   particles), 1 = on, 2 = off                                              */
     double skin_h;              /* cell skin in units of h for K > 1; <= 0 = sized from K                  */
 } sphx_params;
 
@@ -182,6 +182,15 @@ int sphx_ctx_advance(sphx_ctx *ctx, double t_target, int64_t max_steps, sphx_sta
 int sphx_ctx_enqueue_steps(sphx_ctx *ctx, int64_t n_steps);
 int sphx_ctx_sync(sphx_ctx *ctx, sphx_status *status);
 
+/* Steps are replayed as hipGraphs captured per (schedule phase, batch length); a combination that has not come up
+ * before is captured on first use (a few ms).  sphx_ctx_prepare_steps captures, without running anything, what
+ * an sphx_ctx_enqueue_steps(n_steps) / sphx_ctx_advance(.., max_steps = n_steps) issued next would replay, so
+ * that the call itself is pure replay.  sphx_ctx_graph_stats: step slots replayed from graphs / launched
+ * eagerly / graphs captured since creation. */
+int sphx_ctx_prepare_steps(sphx_ctx *ctx, int64_t n_steps);
+int sphx_ctx_graph_stats(sphx_ctx *ctx, int64_t *slots_replayed, int64_t *slots_eager,
+                         int64_t *graphs_captured);
+
 /* Copy state back in the caller's original row order.  Any pointer may be NULL.  rho,p,force,
  * force_prior,Vol,B are those of the last completed step (what integration_verlet / density_correction
  * returned in SPH_Poiseuille.m:254-266). */
@@ -203,16 +212,19 @@ int sphx_ctx_profile_read(sphx_ctx *ctx, int capacity, const char **names, doubl
                           int64_t *launches, int *n_kernels);
 
 /* Average duration (ms) of ONE neighbour-pass kernel ("k_density", "k_kgc", "k_forces", "k_continuity") in
- * the hipGraph-replay regime: `reps` back-to-back launches between two HIP events; state is left unchanged. */
+ * the hipGraph-replay regime: `reps` back-to-back launches between two HIP events.  pos/vel/drho_dt are left
+ * unchanged; the per-step outputs (rho, p, force, Vol, B) are overwritten and cannot be downloaded again until
+ * the next step has been taken. */
 int sphx_ctx_time_kernel(sphx_ctx *ctx, const char *name, int reps, double *avg_ms);
 
-/* The launch shape the context chose (lanes cooperating per particle, steps per hipGraph replay). */
-/* Cell-grid policy in force: rebuild interval K (shrinks by one whenever the device had to stop for an
- * unscheduled re-bin), skin in length units, the number of such unscheduled re-bins so far, and the largest
- * distance of any particle from where it was binned (as of the last advance / sync; must stay <= skin/2). */
+/* Cell-grid policy in force: re-binning interval K (constant), skin in length units, the number of unscheduled
+ * re-binnings so far (the drift bound was hit: host-driven contexts then re-bin every step for a cool-down of
+ * 16..1024 steps, dynamic contexts just re-bin), and the largest distance of any particle from where it was
+ * binned (as of the last advance / sync; always <= skin/2). */
 int sphx_ctx_grid_policy(sphx_ctx *ctx, int *rebuild_every, double *skin, int64_t *forced_rebuilds,
                          double *drift);
 
+/* The launch shape the context chose (lanes cooperating per particle, steps per hipGraph replay). */
 int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph);
 
 /* Global particle counts and the cell grid the context built. */

@@ -31,7 +31,7 @@ class SphxParams(C.Structure):
                                            "gravity_g", "transport_coeff", "t_end")] + \
                [("sort_interval", C.c_int32), ("lanes_per_particle", C.c_int32),
                 ("steps_per_graph", C.c_int32), ("reserved", C.c_int32), ("rebuild_every", C.c_int32),
-                ("reserved2", C.c_int32), ("skin_h", C.c_double)]
+                ("dynamic_rebin", C.c_int32), ("skin_h", C.c_double)]
 
 
 class SphxStatus(C.Structure):
@@ -48,6 +48,7 @@ EXPORTS = [
     "sphx_transport_correction", "sphx_integration_1st", "sphx_integration_2nd",
     "sphx_integration_verlet", "sphx_advance_shell_step", "sphx_wall_shear_monitor",
     "sphx_ctx_create", "sphx_ctx_destroy", "sphx_ctx_advance", "sphx_ctx_enqueue_steps", "sphx_ctx_sync",
+    "sphx_ctx_prepare_steps", "sphx_ctx_graph_stats",
     "sphx_ctx_download", "sphx_ctx_monitor", "sphx_ctx_neighbor_list", "sphx_ctx_profile_enable",
     "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_grid_policy", "sphx_ctx_time_kernel",
     "sphx_slab_create", "sphx_slab_layout", "sphx_slab_local_vmax", "sphx_slab_prepare", "sphx_slab_compute",
@@ -104,7 +105,7 @@ def make_params(prm, t_end=None, transport_coeff=None, lanes_per_particle=0, ste
                       transport_coeff=prm.transport_coeff if transport_coeff is None else transport_coeff,
                       t_end=prm.t_end if t_end is None else t_end, sort_interval=int(prm.sort_interval),
                       lanes_per_particle=int(lanes_per_particle), steps_per_graph=int(steps_per_graph),
-                      reserved=0, rebuild_every=int(rebuild_every), reserved2=int(dynamic_rebin), skin_h=float(skin_h))
+                      reserved=0, rebuild_every=int(rebuild_every), dynamic_rebin=int(dynamic_rebin), skin_h=float(skin_h))
 
 
 class Context:
@@ -150,6 +151,15 @@ class Context:
         st = SphxStatus()
         check(lib().sphx_ctx_sync(self._h, C.byref(st)))
         return st.as_dict()
+
+    def prepare_steps(self, n_steps):
+        """Capture (without running) the graphs the next enqueue_steps(n_steps) / advance(max_steps=n_steps) replays."""
+        check(lib().sphx_ctx_prepare_steps(self._h, C.c_int64(n_steps)))
+
+    def graph_stats(self) -> dict:
+        a, b, g = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().sphx_ctx_graph_stats(self._h, C.byref(a), C.byref(b), C.byref(g)))
+        return dict(slots_replayed=a.value, slots_eager=b.value, graphs_captured=g.value)
 
     def download(self, fields=("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")) -> dict:
         nt = self.n_total

@@ -3,6 +3,7 @@
 
 #include <map>
 #include <mutex>
+#include <unordered_map>
 #include <utility>
 
 namespace sphx {
@@ -44,11 +45,12 @@ size_t pool_class(size_t bytes)
 struct Pool {
     std::mutex m;
     std::multimap<std::pair<int, size_t>, void *> free_blocks;  // (device, class) -> block
+    std::unordered_map<void *, int> owner;                      // block -> the device it was allocated on
     size_t cached = 0;
     static constexpr size_t kMaxCached = (size_t)4 << 30;
     void trim()
     {
-        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+        for (auto &kv : free_blocks) { owner.erase(kv.second); (void)hipFree(kv.second); }
         free_blocks.clear();
         cached = 0;
     }
@@ -90,6 +92,10 @@ void *pool_alloc(size_t bytes)
         e = hipMalloc(&p, cls);
     }
     SPHX_HIP(e);
+    {
+        std::lock_guard<std::mutex> lk(P.m);
+        P.owner[p] = dev;
+    }
     return p;
 }
 
@@ -97,12 +103,16 @@ void pool_free(void *p, size_t bytes)
 {
     if (!p) return;
     const size_t cls = pool_class(bytes);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return; }
     Pool &P = pool();
     std::lock_guard<std::mutex> lk(P.m);
-    if (P.cached + cls > Pool::kMaxCached) { (void)hipFree(p); return; }
-    P.free_blocks.insert({{dev, cls}, p});
+    // a block goes back under the device that allocated it, whatever device is current now
+    auto it = P.owner.find(p);
+    if (it == P.owner.end() || P.cached + cls > Pool::kMaxCached) {
+        if (it != P.owner.end()) P.owner.erase(it);
+        (void)hipFree(p);
+        return;
+    }
+    P.free_blocks.insert({{it->second, cls}, p});
     P.cached += cls;
 }
 

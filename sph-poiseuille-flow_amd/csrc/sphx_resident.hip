@@ -3,9 +3,11 @@
 // MEX-convention pair-list emission, per-kernel HIP-event timing, and the x-slab (multi-GPU) entry
 // points.  The kernels are in sphx_kernels.hpp.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
+#include <map>
 
 #include "sphx_common.hpp"
 #include "sphx_kernels.hpp"
@@ -109,9 +111,13 @@ struct sphx_ctx {
     int n_blocks_particles = 0;  // grid of the LPP kernels (capacity based)
     int n_blocks_flat = 0;       // grid of one-thread-per-particle kernels
 
-    // replayable graphs per rebuild interval K and size: [K][0] holds the full spg-sized graph, [K][1] one period
-    // (2K slots) for short batches; captured on demand (the full one of the configured K at creation)
-    hipGraphExec_t graph_exec[65][2] = {};
+    // Replayable graphs, keyed by the phase they were captured from and their length: {cur, lay, pos, slots}.  A graph
+    // of graph_slots() slots (a multiple of the 2K-step period) hands the phase back unchanged, so a long run replays
+    // ONE graph whatever phase it was entered at; exact-length batches (sphx_ctx_enqueue_steps, advance with
+    // max_steps -- a caller logging every 20 steps) get a graph per (phase, length), captured the first time that
+    // combination comes up (or ahead of time by sphx_ctx_prepare_steps).
+    std::map<std::array<int, 4>, hipGraphExec_t> graphs;
+    int64_t slots_replayed = 0, slots_eager = 0, graphs_captured = 0;
     int64_t chunk_slots = 128;   // slots enqueued between two host looks at the clock (adaptive, see advance)
     bool profiling = false;
     KernelTimer timer;
@@ -153,11 +159,9 @@ struct sphx_ctx {
 
     void drop_graph()
     {
-        for (auto &per_k : graph_exec)
-            for (auto &e : per_k) {
-                if (e) (void)hipGraphExecDestroy(e);
-                e = nullptr;
-            }
+        for (auto &kv : graphs)
+            if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
     }
 
     ~sphx_ctx()
@@ -413,18 +417,32 @@ int graph_slots(const sphx_ctx *c)
     return period * std::max(1, c->spg / period);
 }
 
-// which: 0 = the full graph (graph_slots), 1 = one period (2K slots)
-void build_graph(sphx_ctx *c, int which)
+constexpr int kMinGraphSlots = 4;    // shorter exact batches are launched eagerly (a replay costs ~50 us of host time)
+constexpr size_t kMaxGraphs = 96;    // cache bound: 2 * 2 * K phases for a caller with one cadence, K <= 16 in practice
+
+// the graph of `n` step slots entered at phase (cur, lay, pos) of the static schedule (dynamic contexts: only cur matters)
+hipGraphExec_t get_graph(sphx_ctx *c, int cur, int lay, int pos, int n)
 {
-    const int K = c->rebuild_every, n = which ? (c->dyn ? 2 : 2 * K) : graph_slots(c);
-    if (c->graph_exec[K][which]) return;
+    const std::array<int, 4> key{cur, c->dyn ? 0 : lay, c->dyn ? 0 : pos, n};
+    auto it = c->graphs.find(key);
+    if (it != c->graphs.end()) return it->second;
+    if (c->graphs.size() >= kMaxGraphs) c->drop_graph();
+    const int K = c->rebuild_every;
     const bool prof = c->profiling;
     c->profiling = false;
     SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     try {
+        int q = cur, l = lay, p = pos;
         for (int j = 0; j < n; ++j) {
-            if (c->dyn) launch_step_dyn(c, j & 1);
-            else launch_step(c, j & 1, (j / K) & 1, j % K, (j % K) == K - 1);
+            if (c->dyn) {
+                launch_step_dyn(c, q);
+            } else {
+                const bool rebuild = p == K - 1;
+                launch_step(c, q, l, p, rebuild);
+                if (rebuild) { l ^= 1; p = 0; }
+                else ++p;
+            }
+            q ^= 1;
         }
     } catch (...) {
         hipGraph_t junk = nullptr;
@@ -436,36 +454,55 @@ void build_graph(sphx_ctx *c, int which)
     c->profiling = prof;
     hipGraph_t g = nullptr;
     SPHX_HIP(hipStreamEndCapture(c->stream, &g));
-    const hipError_t e = hipGraphInstantiate(&c->graph_exec[K][which], g, nullptr, nullptr, 0);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     SPHX_HIP(e);
+    c->graphs[key] = exec;
+    c->graphs_captured += 1;
+    return exec;
 }
 
-// Enqueue `slots` step slots from the current (cur, lay, pos); slots that find run[q]==0 are no-ops.  Whole
-// graphs are replayed whenever the state is the one the graph was captured from, single slots are launched
-// eagerly otherwise.  The host copies of cur/lay/pos advance as if every slot executed; read_clock() recomputes
-// them from the executed step count.
-void enqueue_slots(sphx_ctx *c, int64_t slots)
+// Enqueue `slots` step slots from the current (cur, lay, pos); slots that find run[q]==0 are no-ops.  Whole graphs
+// are replayed from ANY phase of the static schedule (see sphx_ctx::graphs); what is left over is launched eagerly,
+// or -- exact_tail: the caller asked for exactly this many steps -- replayed as a graph of its own.  Only a cool-down
+// (every slot re-bins, see slot_rebuilds) runs eagerly throughout.  The host copies of cur/lay/pos advance as if
+// every slot executed; read_clock() recomputes them from the executed step count.
+// capture_only: build the graphs this call would replay, launch nothing (sphx_ctx_prepare_steps).
+void enqueue_slots(sphx_ctx *c, int64_t slots, bool exact_tail, bool capture_only = false)
 {
     int64_t left = slots;
+    // capture_only walks the phases on copies
+    const int cur0 = c->cur, lay0 = c->lay, pos0 = c->pos, out_lay0 = c->out_lay;
+    const int64_t prov0 = c->prov_step;
     while (left > 0) {
         const int per_graph = graph_slots(c);
         const bool steady = c->prov_step >= c->cool_until;
-        const int period = c->dyn ? 2 : 2 * c->rebuild_every;
-        if (!c->profiling && steady && c->cur == 0 && c->lay == 0 && c->pos == 0 && left >= period) {
-            const int which = left >= per_graph ? 0 : 1;  // short batches: one period at a time
-            const int n = which ? period : per_graph;
-            build_graph(c, which);
-            SPHX_HIP(hipGraphLaunch(c->graph_exec[c->rebuild_every][which], c->stream));
-            left -= n;  // back at (0,0,0); the last slot was a rebuild out of layout 1
-            c->prov_step += n;
-            c->out_lay = c->dyn ? 0 : 1;
+        int n = 0;
+        if (!c->profiling && steady) {
+            if (left >= per_graph) n = per_graph;
+            else if (exact_tail && left >= kMinGraphSlots) n = (int)left;
+        }
+        if (n > 0) {
+            hipGraphExec_t exec = get_graph(c, c->cur, c->lay, c->pos, n);
+            if (!capture_only) {
+                SPHX_HIP(hipGraphLaunch(exec, c->stream));
+                c->slots_replayed += n;
+            }
+            for (int k = 0; k < n; ++k) track_step(c);
+            left -= n;
             continue;
         }
-        if (c->dyn) launch_step_dyn(c, c->cur);
-        else launch_step(c, c->cur, c->lay, c->pos, slot_rebuilds(c));
+        if (!capture_only) {
+            if (c->dyn) launch_step_dyn(c, c->cur);
+            else launch_step(c, c->cur, c->lay, c->pos, slot_rebuilds(c));
+            c->slots_eager += 1;
+        }
         track_step(c);
         --left;
+    }
+    if (capture_only) {
+        c->cur = cur0; c->lay = lay0; c->pos = pos0; c->out_lay = out_lay0; c->prov_step = prov0;
     }
     SPHX_HIP(hipGetLastError());
 }
@@ -789,8 +826,8 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     c->skin = skin;
     // Dynamic re-binning pays where a handful of empty launches per step is noise next to the passes (measured: the
     // host-driven forced rebuilds + cool-downs cost 10-25 % of the sustained rate from 0.5 M particles up).
-    // reserved2: 0 = by size, 1 = on, 2 = off.
-    c->dyn = skin > 0.0 && (prm->reserved2 == 1 || (prm->reserved2 == 0 && nf >= 1000000));
+    // dynamic_rebin: 0 = by size, 1 = on, 2 = off.
+    c->dyn = skin > 0.0 && (prm->dynamic_rebin == 1 || (prm->dynamic_rebin == 0 && nf >= 1000000));
 
     // grid: exact periodic tiling in x (cells >= 2h + skin), rows of 2h + skin in y over fluid + wall extent
     double y_min, y_max;
@@ -825,10 +862,7 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     read_clock(c);
     // capture the step graphs now, not inside somebody's timed region (a few ms) -- unless this context can never
     // step (the one-shot contexts behind sphx_neighbor_search)
-    if (prm->t_end > t0) {
-        build_graph(c, 0);
-        if (graph_slots(c) != 2 * c->rebuild_every) build_graph(c, 1);
-    }
+    if (prm->t_end > t0) (void)get_graph(c, c->cur, c->lay, c->pos, graph_slots(c));
 }
 
 // emit the MEX-convention pair list of the current ordering into the ctx-held buffers
@@ -922,11 +956,12 @@ SPHX_EXPORT int sphx_ctx_advance(sphx_ctx *c, double t_target, int64_t max_steps
         want = std::min(want, (double)c->chunk_slots);
         int64_t slots = (int64_t)want;
         const int per_graph = graph_slots(c);
-        if (max_steps > 0 && slots >= max_steps) slots = max_steps;  // exact: no no-op slots
+        bool exact = false;
+        if (max_steps > 0 && slots >= max_steps) { slots = max_steps; exact = true; }  // exact: no no-op slots
         else if (!c->profiling && slots > per_graph) slots = ((slots + per_graph - 1) / per_graph) * per_graph;
         if (slots < 1) slots = 1;
         const int64_t step_before = c->h_clock->step;
-        enqueue_slots(c, slots);
+        enqueue_slots(c, slots, exact);
         read_clock(c);
         const int64_t executed = c->h_clock->step - step_before;
         c->chunk_slots = c->h_clock->need_rebuild ? 64 : std::min<int64_t>(4096, 2 * c->chunk_slots);
@@ -956,8 +991,32 @@ SPHX_EXPORT int sphx_ctx_enqueue_steps(sphx_ctx *c, int64_t n_steps)
     // out the grid and takes the steps that are still owed
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end,
                        (long long)n_steps, c->cur, (const double *)nullptr);
-    enqueue_slots(c, n_steps);
+    enqueue_slots(c, n_steps, true);
     c->pending_target = std::max<int64_t>(c->pending_target, c->h_clock->step) + n_steps;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_ctx_prepare_steps(sphx_ctx *c, int64_t n_steps)
+{
+    SPHX_TRY
+    require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    require(!c->is_slab, "SPHX:Ctx:slab", "slab contexts are advanced with sphx_slab_run");
+    require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
+    read_clock(c);  // the phase the next batch starts from
+    if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
+    enqueue_slots(c, n_steps, true, true);
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_ctx_graph_stats(sphx_ctx *c, int64_t *slots_replayed, int64_t *slots_eager, int64_t *graphs_captured)
+{
+    SPHX_TRY
+    require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    if (slots_replayed) *slots_replayed = c->slots_replayed;
+    if (slots_eager) *slots_eager = c->slots_eager;
+    if (graphs_captured) *graphs_captured = c->graphs_captured;
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -981,7 +1040,7 @@ SPHX_EXPORT int sphx_ctx_sync(sphx_ctx *c, sphx_status *status)
         const int64_t n = std::min(owed, c->chunk_slots);
         hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end, (long long)n,
                            c->cur, (const double *)nullptr);
-        enqueue_slots(c, n);
+        enqueue_slots(c, n, false);
         read_clock(c);
         if (!c->h_clock->need_rebuild) c->chunk_slots = std::min<int64_t>(4096, 2 * c->chunk_slots);
     }
@@ -1620,6 +1679,9 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         float ms = 0.f;
         SPHX_HIP(hipEventElapsedTime(&ms, a, b));
         *avg_ms = (double)ms / reps;
+        // the timed passes overwrote the per-step outputs (rho, p, force, Vol, B) with values of a step that was never
+        // taken: they are not downloadable until the next real step has produced them again
+        c->have_step_outputs = false;
     } catch (...) {
         c->profiling = prof;
         if (a) (void)hipEventDestroy(a);

@@ -133,6 +133,66 @@ def test_cool_downs_follow_a_fixed_schedule(case, capi):
         assert np.array_equal(A[k], Bd[k]), k
 
 
+def test_graphs_replay_from_any_phase(case, capi):
+    """A caller with a fixed cadence (the reference logs every 20 steps, SPH_Poiseuille.m:285-291) enters the schedule
+    at a different phase on every call: each (phase, length) gets its graph once, after that every call is pure
+    replay -- and gives the bits of one long call."""
+    prm, parts = case
+    with _ctx(capi, prm, parts, rebuild_every=8) as a:  # K = 8, 20-step calls: pos cycles 0, 4, 0, ... and lay flips
+        a.advance(1e9, max_steps=5)                     # start misaligned (pos = 5)
+        for _ in range(8):
+            a.advance(1e9, max_steps=20)
+        warm = a.graph_stats()
+        for _ in range(8):
+            st = a.advance(1e9, max_steps=20)
+        hot = a.graph_stats()
+        A = a.download(fields=("pos", "vel", "drho_dt"))
+    assert st["step"] == 5 + 16 * 20
+    assert hot["graphs_captured"] == warm["graphs_captured"]                 # nothing new to capture
+    assert hot["slots_eager"] == warm["slots_eager"]                         # and nothing launched eagerly
+    assert hot["slots_replayed"] - warm["slots_replayed"] == 8 * 20
+    with _ctx(capi, prm, parts, rebuild_every=8) as b:
+        b.advance(1e9, max_steps=5 + 16 * 20)
+        Bd = b.download(fields=("pos", "vel", "drho_dt"))
+    for k in A:
+        assert np.array_equal(A[k], Bd[k]), k
+
+
+def test_graphs_replay_after_a_forced_rebuild(case, capi):
+    """A forced rebuild flips the state parity without taking a step; with an even K the context then never returns
+    to the phase its first graph was captured from.  It must keep replaying graphs all the same."""
+    prm, parts = case
+    with _ctx(capi, prm, parts, rebuild_every=8, skin_h=0.03, lanes_per_particle=4) as ctx:
+        ctx.advance(1e9, max_steps=12)
+        assert ctx.grid_policy()["forced_rebuilds"] >= 1
+    # a skin that is adequate most of the time: forced rebuilds are rare events followed by a 16-step cool-down
+    with _ctx(capi, prm, parts, rebuild_every=8, skin_h=0.25, steps_per_graph=16) as ctx:
+        ctx.advance(1e9, max_steps=3000)
+        pol, g0 = ctx.grid_policy(), ctx.graph_stats()
+        ctx.advance(1e9, max_steps=1600)
+        g1 = ctx.graph_stats()
+        forced_in_window = ctx.grid_policy()["forced_rebuilds"] - pol["forced_rebuilds"]
+    replayed, eager = g1["slots_replayed"] - g0["slots_replayed"], g1["slots_eager"] - g0["slots_eager"]
+    assert replayed + eager >= 1600
+    # eager slots: cool-downs (<= 16..1024 steps per forced rebuild) and the empty slots behind each stop only
+    assert replayed >= 1600 - forced_in_window * 1100 - 64 and (forced_in_window > 0 or eager == 0), (g0, g1, pol)
+
+
+def test_prepare_steps_makes_the_next_batch_pure_replay(case, capi):
+    prm, parts = case
+    with _ctx(capi, prm, parts) as ctx:
+        ctx.enqueue_steps(5)
+        ctx.sync()
+        ctx.prepare_steps(20)
+        g0 = ctx.graph_stats()
+        ctx.enqueue_steps(20)
+        st = ctx.sync()
+        g1 = ctx.graph_stats()
+    assert st["step"] == 25
+    assert g1["graphs_captured"] == g0["graphs_captured"] and g1["slots_eager"] == g0["slots_eager"]
+    assert g1["slots_replayed"] - g0["slots_replayed"] == 20
+
+
 @pytest.mark.parametrize("n_steps", [1, 2, 3, 4, 5, 6])
 def test_pair_list_between_rebuilds(case, capi, oracle, n_steps):
     """The MEX-convention pair list taken from a stale (but still valid) grid equals a fresh search."""
