@@ -142,7 +142,11 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
             alg = BYTES_PER_FLUID.get(dom, 0) * nf + BYTES_PER_WALL.get(dom, 0) * nw
             achieved = alg / (ms * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(name, dom), launch_ms=ms, launch_ms_eager=ms_eager,
+                        frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(name, dom),
+                        traffic_source="profiles/pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch from separate "
+                                       "rocprofv3 --pmc passes of this kernel on this workload, committed -- not "
+                                       "collected in this run (counters need the profiler)",
+                        launch_ms=ms, launch_ms_eager=ms_eager,
                         algorithmic_bytes=alg,
                         step_achieved=(STEP_BYTES_FLUID * nf + STEP_BYTES_WALL * nw) * steps / seconds / 1e9)
     tuning.update(ctx.grid_policy())

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["sphx_common.hip", "sphx_pairlist.hip", "sphx_resident.hip"]
 HEADERS = ["sphx_common.hpp", "sphx_device.hpp", "sphx_kernels.hpp", os.path.join("..", "..", "include", "sphx.h")]
 LIB = os.path.join(CSRC, "libsphx.so")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics",
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 

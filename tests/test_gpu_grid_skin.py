@@ -138,7 +138,7 @@ def test_graphs_replay_from_any_phase(case, capi):
     at a different phase on every call: each (phase, length) gets its graph once, after that every call is pure
     replay -- and gives the bits of one long call."""
     prm, parts = case
-    with _ctx(capi, prm, parts, rebuild_every=8) as a:  # K = 8, 20-step calls: pos cycles 0, 4, 0, ... and lay flips
+    with _ctx(capi, prm, parts, rebuild_every=8, skin_h=0.8) as a:  # K = 8, 20-step calls: pos cycles 5, 1, 5, ... and lay flips
         a.advance(1e9, max_steps=5)                     # start misaligned (pos = 5)
         for _ in range(8):
             a.advance(1e9, max_steps=20)
@@ -151,7 +151,7 @@ def test_graphs_replay_from_any_phase(case, capi):
     assert hot["graphs_captured"] == warm["graphs_captured"]                 # nothing new to capture
     assert hot["slots_eager"] == warm["slots_eager"]                         # and nothing launched eagerly
     assert hot["slots_replayed"] - warm["slots_replayed"] == 8 * 20
-    with _ctx(capi, prm, parts, rebuild_every=8) as b:
+    with _ctx(capi, prm, parts, rebuild_every=8, skin_h=0.8) as b:
         b.advance(1e9, max_steps=5 + 16 * 20)
         Bd = b.download(fields=("pos", "vel", "drho_dt"))
     for k in A:
@@ -180,7 +180,7 @@ def test_graphs_replay_after_a_forced_rebuild(case, capi):
 
 def test_prepare_steps_makes_the_next_batch_pure_replay(case, capi):
     prm, parts = case
-    with _ctx(capi, prm, parts) as ctx:
+    with _ctx(capi, prm, parts, rebuild_every=8, skin_h=0.8) as ctx:  # a skin no early transport shift outruns
         ctx.enqueue_steps(5)
         ctx.sync()
         ctx.prepare_steps(20)
