@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libsphx.so")
+LIB_PATH = os.environ.get("SPHX_LIB") or os.path.join(HERE, "csrc", "libsphx.so")  # SPHX_LIB: experiment builds
 _dp = C.POINTER(C.c_double)
 
 SPHX_OK = 0

@@ -34,6 +34,12 @@
 //     kernel also decides when to re-bin and the re-binning kernels of every step skip themselves otherwise
 //     (slot_active, clock_step).
 #pragma once
+#include <type_traits>
+
+#ifndef SPHX_EXPERIMENT
+#define SPHX_EXPERIMENT 0
+#endif
+
 #include "sphx_device.hpp"
 
 namespace sphx {
@@ -247,6 +253,9 @@ __global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_st
 // particle was three of them).
 // ---------------------------------------------------------------------------------------------
 constexpr int kWallBit = 1 << 30;
+// nl_cnt[lane]: rows this lane owns (low half) and how many of them, the first ones, hold fluid neighbours (high half)
+__device__ __forceinline__ int list_rows(int packed) { return packed & 0xffff; }
+__device__ __forceinline__ int list_fluid_rows(int packed) { return packed >> 16; }
 
 // Prologue shared by the passes: everything whose address does not depend on the clock is requested
 // BEFORE the run flag is looked at, so the clock read overlaps the particle's own loads.
@@ -276,7 +285,7 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
     // at 32 lanes per particle): count -> entry -> position becomes {count, entries} -> position
     int ns = 0, e_row0 = 0, e_row1 = 0;
     if (MODE == 2) {
-        ns = t.sl_cnt[tid];
+        ns = list_rows(t.sl_cnt[tid]);
         e_row0 = t.sl_idx[tid];
         e_row1 = t.sl_idx[(size_t)t.nl_stride + tid];
     }
@@ -284,7 +293,7 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
     double s_in = 0.0, s_ct = 0.0;
-    int cnt = 0, scnt = 0;
+    int cnt = 0, scnt = 0, cnt_fl = 0, scnt_fl = 0;
     const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
     const int row_base = tid - sub;  // list column of lane 0 of this group
     // the LPP lanes of a particle test LPP consecutive candidates at a time (uniform trip count over the
@@ -352,9 +361,19 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
                         else s_in += W;
                     }
                 }
-                push(acc, e);
+                // wall candidates sit behind the fluid ones: the fluid count is the count reached before the first row
+                // that holds a wall entry, plus that row's accepted fluid entries
+                const bool wall_row = (e & kWallBit) != 0;
+                if (!__any(wall_row)) {
+                    push(acc, e);
+                    cnt_fl = cnt;
+                } else {
+                    cnt_fl += LPP == 1 ? ((acc && !wall_row) ? 1 : 0) : __popc(group_bits(acc && !wall_row));
+                    push(acc, e);
+                }
             }
             if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
+            cnt_fl = min(cnt_fl, cnt);
         }
     } else if (active) {
         const double xi = pi.x, yi = pi.y;
@@ -402,6 +421,8 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
             push(acc, k);
             if (record) push_super(wide, k);
         }
+        cnt_fl = cnt;
+        scnt_fl = scnt;
         if (near_wall) {
             const int w0 = whi[0] - wlo[0], w1 = whi[1] - wlo[1], w2 = whi[2] - wlo[2];
             const int nwl = w0 + w1 + w2;
@@ -426,12 +447,17 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
             }
         }
         if (cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
+        cnt_fl = min(cnt_fl, cnt);
         if (record && scnt > t.sl_cap * LPP) { atomicOr(t.flags, 1); scnt = t.sl_cap * LPP; }
+        scnt_fl = min(scnt_fl, scnt);
     }
     // cnt is the particle's neighbour count (identical in all lanes of the group); lane `sub` owns entries
-    // sub, sub+LPP, ...
-    if (tid < t.nl_stride) t.nl_cnt[tid] = cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0;
-    if (record && tid < t.nl_stride) t.sl_cnt[tid] = scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0;
+    // sub, sub+LPP, ...  Fluid neighbours come first (cnt_fl of them), so a lane's rows are its fluid rows followed by
+    // its wall rows: both counts are stored (list_rows / list_fluid_rows).
+    if (tid < t.nl_stride)
+        t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
+    if (record && tid < t.nl_stride)
+        t.sl_cnt[tid] = (scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0) | ((scnt_fl > sub ? (scnt_fl - sub + LPP - 1) / LPP : 0) << 16);
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {
@@ -467,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
 {
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
-    const int nn_all = t.nl_cnt[tid];
+    const int nn_all = list_rows(t.nl_cnt[tid]);
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
     // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
@@ -523,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     const double4 ai = in_cap ? t.a[i] : make_double4(1.0, 0.0, 0.0, 0.0);
     const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
     const double mi = in_cap ? s.mass[i] : 1.0;
-    const int nn_all = t.nl_cnt[tid];
+    const int nn_all = list_rows(t.nl_cnt[tid]);
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
     // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
@@ -635,6 +661,487 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
             if (d2 != d2) d2 = INFINITY;
         }
         t.posn[i] = make_double2(g.periodic ? wrap_x(xo, ph.DL) : xo, yo);  // a slab wraps when particles change owner
+        t.veln[i] = make_double2(vxn, vyn);
+        t.fp[i] = make_double2(fpx, fpy);
+        t.f[i] = make_double2(fx, fy);
+    }
+    // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off));
+    __shared__ double s_d2[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_d2[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_d2[0];
+        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_d2[k]);
+        t.dpart[blk] = m;
+    }
+}
+
+// =================================================================================================
+// Large channels (few lanes per particle, LPP <= 8): the "_w" variants of passes B, CD and E.
+// Counters of the round-1 kernels at 0.5-6 M particles: VALU 55-75 % busy, texture addresser 60-90 %, and a wave
+// spending ~5 x its own issue time in flight -- every trip of the walk was two dependent memory round trips
+// (list entry -> neighbour records) followed by 55-100 VALU instructions under per-entry fluid/wall and kernel-piece
+// branches.  Here
+//   * list entries run three rows ahead of their use (one register each): one round trip per trip;
+//   * fluid and wall neighbours have loops of their own (fluid entries come first in a lane's rows, pass A stores both
+//     row counts) -- no per-entry branch, no pointer selects;
+//   * the minimum-image fold runs only in wavefronts holding a particle near the periodic seam;
+//   * the kernel derivative is branch-free, 1/sqrt and the viscous division are Newton-refined hardware estimates;
+//   * the force pass can stage its tile's neighbourhood in LDS (TILE > 0), see k_forces_w.
+// Small channels keep the compact kernels above: at a few thousand particles a pass is a chain of dependent round
+// trips and code size (instruction-cache fill per launch) matters more than instruction count.
+// =================================================================================================
+
+// A neighbour's x can be a period away from the particle's only if one of them was binned in the first or last cell
+// column and has since been wrapped; particles whose x lies within 2.5 columns of either end of the period cover every
+// such pair (a column is wider than the skin, so a particle binned in column <= 1 is still left of 2.5 columns).
+__device__ __forceinline__ bool near_seam(const Grid &g, double x)
+{
+    const double w = 2.5 / g.inv_csx;
+    return g.periodic && (x < w || x > g.DL - w);
+}
+
+// Rows [0, rows_fl) of this lane's list column hold fluid neighbours: body(k) for each, entries three rows ahead.
+template <typename Body>
+__device__ __forceinline__ void walk_fluid_rows(const FluidTmp &t, int tid, int rows_fl, int e_row0, int e_row1, Body &&body)
+{
+    if (rows_fl <= 0) return;
+    int ea = e_row0, eb = e_row1;
+    int ec = rows_fl > 2 ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
+    for (int m = 0; m < rows_fl; ++m) {
+        const int ed = m + 3 < rows_fl ? t.nl_idx[(size_t)(m + 3) * t.nl_stride + tid] : 0;
+        body(ea);
+        ea = eb; eb = ec; ec = ed;
+    }
+}
+
+// Rows [rows_fl, rows) hold wall neighbours (only next to a wall): body(k)
+template <typename Body>
+__device__ __forceinline__ void walk_wall_rows(const FluidTmp &t, int tid, int rows_fl, int rows, Body &&body)
+{
+    for (int m = rows_fl; m < rows; ++m) body(t.nl_idx[(size_t)m * t.nl_stride + tid] & (kWallBit - 1));
+}
+
+// LDS tile of a neighbour pass.  The workgroup's particles are consecutive in cell order -- a run of cells of one
+// column -- and every fluid neighbour (or superset candidate) of theirs was binned into the same rows (+-1) of the three
+// columns around it: three CONTIGUOUS index ranges.  The first `cap` particles of those ranges (own column first) are
+// copied into LDS with coalesced loads once per workgroup and the walk gathers from there; a neighbour outside the staged
+// ranges (a tile running across a column end, ranges longer than the tile) is read from global memory, so results do
+// not depend on the tile size, bit for bit.  Measured (us per launch, with / without the tile):
+//   6 M particles, 2 lanes per particle: forces 607 / 872, KGC 295 / 320, continuity 375 / 452, pass A walk 475 / 434
+//   6 M particles, 4 lanes            : forces 673 / 740, KGC 372 / 344, continuity 465 / 446, pass A walk 511 / 451
+//   0.5 M particles, 2 lanes          : forces 57.1 / 64.2, KGC 33.1 / 29.0, continuity 36.7 / 37.0, walk 51.8 / 46.6
+// -- the fewer lanes share a particle the less its global gathers coalesce, and only records of >= 40 bytes per neighbour
+// repay the staging: the force pass always uses the tile, KGC and continuity at 2 lanes per particle on channels that do
+// not fit the Infinity Cache, pass A never.  (The 6 M figures without entries running ahead: 803 with / 784 without --
+// the exposed round trip was the list entry, not the gather.)
+struct TileMap {
+    int lo0, lo1, lo2, len0, len1, len2;
+    __device__ __forceinline__ int total() const { return len0 + len1 + len2; }
+    __device__ __forceinline__ int index(int sl) const  // staged slot -> particle
+    {
+        return sl < len0 ? lo0 + sl : (sl < len0 + len1 ? lo1 + (sl - len0) : lo2 + (sl - len0 - len1));
+    }
+    __device__ __forceinline__ int slot(int k) const  // particle -> staged slot, -1: not staged
+    {
+        const unsigned u0 = (unsigned)(k - lo0), u1 = (unsigned)(k - lo1), u2 = (unsigned)(k - lo2);
+        return u0 < (unsigned)len0 ? (int)u0 : (u1 < (unsigned)len1 ? len0 + (int)u1 : (u2 < (unsigned)len2 ? len0 + len1 + (int)u2 : -1));
+    }
+};
+
+template <int LPP>
+__device__ __forceinline__ TileMap tile_ranges(const Grid &g, const FluidSet &s, int blk, int n_now, int cap)
+{
+    TileMap tm{0, 0, 0, 0, 0, 0};
+    constexpr int per_tile = kBlock / LPP;
+    const int p_first = blk * per_tile;
+    if (p_first >= n_now) return tm;
+    const int p_last = min(p_first + per_tile, n_now) - 1;
+    const int c_first = s.cell[p_first], c_last = s.cell[p_last];
+    const int cx = c_first / g.ncy, r_lo = c_first - cx * g.ncy;
+    const int r_hi = (c_last / g.ncy == cx) ? c_last - cx * g.ncy : g.ncy - 1;  // the tile's part in column cx
+    const int ra = max(r_lo - 1, 0), rb = min(r_hi + 1, g.ncy - 1) + 1;
+    int lo[3], len[3];
+#pragma unroll
+    for (int ox = -1; ox <= 1; ++ox) {
+        int col = cx + ox;
+        bool ok = true;
+        if (g.periodic) {
+            if (col < 0) col += g.ncx;
+            else if (col >= g.ncx) col -= g.ncx;
+        } else if (col < 0 || col >= g.ncx) {
+            ok = false;
+        }
+        const int a0 = ok ? s.start[col * g.ncy + ra] : 0, a1 = ok ? s.start[col * g.ncy + rb] : 0;
+        lo[ox + 1] = a0;
+        len[ox + 1] = a1 - a0;
+    }
+    tm.lo0 = lo[1]; tm.len0 = min(len[1], cap);
+    tm.lo1 = lo[0]; tm.len1 = min(len[0], cap - tm.len0);
+    tm.lo2 = lo[2]; tm.len2 = min(len[2], cap - tm.len0 - tm.len1);
+    return tm;
+}
+
+// tile capacity in particles: the three-column neighbourhood of kBlock / LPP particles at ~9 particles per cell
+__host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : (lpp == 4 ? 320 : 448); }
+
+// pass A, walking the superset list (see density_body MODE 2).  The LPP lanes of a particle test one list row at a
+// time and pack the accepted entries with ballot + popcount, so a group's trip count is uniform: the rows in which all
+// of its lanes hold fluid candidates run a branch-free fluid body with the entries three rows ahead, the (at most one
+// mixed + the wall) rows behind them run the general body.
+// (No LDS tile here: staging the candidate positions made this pass 10 % slower at 0.5 M and at 6 M particles -- it
+// gathers 16 bytes per candidate, too little for the staging to pay.)
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+                                                      FluidTmp t, Walls w, int cond_fresh)
+{
+    if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
+    SPHX_PASS_INDEX();
+    const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const bool lead = in_cap && sub == 0;
+    const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
+    const int spacked = t.sl_cnt[tid];
+    const int e_row0 = t.sl_idx[tid], e_row1 = t.sl_idx[(size_t)t.nl_stride + tid];
+    const double dt = clk->dt;
+    if (!clk->run[q]) return;
+    const bool active = i < clk->n;
+    const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
+    const int row_base = tid - sub;
+    const int half_shift = gbase & 31;
+    const unsigned grp_mask = LPP >= 32 ? 0xffffffffu : ((1u << (LPP & 31)) - 1u);
+    const unsigned below_me = (1u << sub) - 1u;
+    auto group_bits = [&](bool acc) -> unsigned {
+        const unsigned long long bal = __ballot(acc);
+        const unsigned half = lane < 32 ? (unsigned)bal : (unsigned)(bal >> 32);
+        return (half >> half_shift) & grp_mask;
+    };
+    int cnt = 0;
+    auto push = [&](bool acc, int entry) {
+        const unsigned grp = LPP == 1 ? (acc ? 1u : 0u) : group_bits(acc);
+        if (acc) {
+            const int m = cnt + __popc(grp & below_me);
+            if (m / LPP < t.nl_cap) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+        }
+        cnt += __popc(grp);
+    };
+    const int ns = active ? list_rows(spacked) : 0;
+    // group-uniform trip counts: lane 0 of the group owns the most rows, its last lane the fewest fluid rows
+    const int rows_all = LPP == 1 ? ns : __shfl(ns, gbase);
+    const int my_fl = active ? list_fluid_rows(spacked) : 0;
+    const int rows_fl = LPP == 1 ? my_fl : __shfl(my_fl, gbase + LPP - 1);
+    const double xi = pi.x, yi = pi.y;
+    double s_in = 0.0, s_ct = 0.0;
+    int ea = e_row0, eb = e_row1;
+    int ec = rows_fl > 2 ? t.sl_idx[2 * (size_t)t.nl_stride + tid] : 0;
+    auto fluid_rows = [&](auto fold) {
+        for (int m = 0; m < rows_fl; ++m) {
+            const int ed = m + 3 < rows_fl ? t.sl_idx[(size_t)(m + 3) * t.nl_stride + tid] : 0;
+            const double2 pj = s.pos[ea];
+            double dx = xi - pj.x;
+            if (decltype(fold)::value) dx = min_image(g, dx);
+            const double dy = yi - pj.y;
+            const double r2 = dx * dx + dy * dy;
+            const bool acc = r2 > kR2Min && r2 < ph.kc.rcut2;
+            const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));  // (NaN for a coincident pair: discarded by the select)
+            s_in += acc ? W : 0.0;
+            push(acc, ea);
+            ea = eb; eb = ec; ec = ed;
+        }
+    };
+    if (__any(active && near_seam(g, xi))) fluid_rows(std::true_type{});
+    else fluid_rows(std::false_type{});
+    int cnt_fl = cnt;
+    for (int m = rows_fl; m < rows_all; ++m) {  // the mixed row and the wall rows
+        bool acc = false, wall = false;
+        int e = 0;
+        if (m < ns) {
+            e = t.sl_idx[(size_t)m * t.nl_stride + tid];
+            wall = (e & kWallBit) != 0;
+            const int k = e & (kWallBit - 1);
+            const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
+            const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
+            const double r2 = dx * dx + dy * dy;
+            if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+                acc = true;
+                const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
+                if (wall) s_ct += W * w.a[k].x;
+                else s_in += W;
+            }
+        }
+        cnt_fl += LPP == 1 ? ((acc && !wall) ? 1 : 0) : __popc(group_bits(acc && !wall));
+        push(acc, e);
+    }
+    if (active && cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
+    cnt_fl = min(cnt_fl, cnt);
+    if (tid < t.nl_stride)
+        t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
+    s_in = group_sum<LPP>(s_in);
+    s_ct = group_sum<LPP>(s_ct);
+    if (active && sub == 0) {
+        const double rho = density_from_sigma(ph.w0 + s_in, s_ct, mass_i, ph.rho0, ph.inv_sigma0);
+        double rhoh = rho + 0.5 * dt * drho_i;
+        if (rhoh < 1e-10) rhoh = ph.rho0;
+        t.a[i] = make_double4(mass_i / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho);
+        t.vol[i] = mass_i / rho;
+    }
+}
+
+// pass B (see k_kgc)
+template <int LPP, int TILE>
+__global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+                                                  FluidTmp t, Walls w)
+{
+    constexpr int kSlots = TILE > 0 ? TILE : 1;
+    __shared__ double2 c_pos[kSlots];
+    __shared__ double c_vol[kSlots];
+    SPHX_PASS_INDEX();
+    const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const int packed = t.nl_cnt[tid];
+    const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
+    if (!clk->run[q]) return;
+    const int n_now = clk->n;
+    const bool active = i < n_now;
+    TileMap tm{0, 0, 0, 0, 0, 0};
+    if (TILE > 0) {
+        tm = tile_ranges<LPP>(g, s, blk, n_now, TILE);
+        for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
+            const int k = tm.index(sl);
+            c_pos[sl] = s.pos[k];
+            c_vol[sl] = t.vol[k];
+        }
+        __syncthreads();
+    }
+    // (early return, not if/else: the compiler would merge the two arms into one FLAT load through a selected pointer)
+    auto fetch = [&](int k, double2 &pj, double &Volj) {
+        if (TILE > 0) {
+            const int slot = tm.slot(k);
+            if (slot >= 0) { pj = c_pos[slot]; Volj = c_vol[slot]; return; }
+        }
+        pj = s.pos[k]; Volj = t.vol[k];
+    };
+    const int rows = active ? list_rows(packed) : 0, rows_fl = active ? list_fluid_rows(packed) : 0;
+    const double xi = pi.x, yi = pi.y;
+    double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
+    auto term = [&](double dx, double dy, double Volj) {
+#if SPHX_EXPERIMENT == 1   /* memory only */
+        a11 += dx; a12 += dy; a21 += Volj;
+#else
+        const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
+        const double ex = dx * inv_r, ey = dy * inv_r;
+        const double fxj = spline_dW_sel(ph.kc, r) * Volj;
+        a11 -= dx * (fxj * ex);
+        a12 -= dx * (fxj * ey);
+        a21 -= dy * (fxj * ex);
+        a22 -= dy * (fxj * ey);
+#endif
+    };
+#if SPHX_EXPERIMENT == 2   /* compute only: no gathers */
+    walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+        term(xi - (double)(k & 7) * 1e-3 - 1e-4, yi - (double)(k & 3) * 1e-3, 1e-5);
+    });
+#elif SPHX_EXPERIMENT == 3   /* gathers only, list entries synthetic: neighbours i-8..i+8 */
+    for (int m = 0; m < rows_fl; ++m) {
+        const int k = max(0, min(t.cap - 1, i + (m * LPP + sub) - 10));
+        const double2 pj = s.pos[k];
+        term(xi - pj.x + 1e-4, yi - pj.y, t.vol[k]);
+    }
+#else
+    if (__any(active && near_seam(g, xi)))
+        walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+            double2 pj; double Volj;
+            fetch(k, pj, Volj);
+            term(min_image(g, xi - pj.x), yi - pj.y, Volj);
+        });
+    else
+        walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+            double2 pj; double Volj;
+            fetch(k, pj, Volj);
+            term(xi - pj.x, yi - pj.y, Volj);
+        });
+#endif
+    walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
+        const double2 pj = w.pos[k];
+        term(min_image(g, xi - pj.x), yi - pj.y, w.a[k].x);
+    });
+    a11 = group_sum<LPP>(a11);
+    a12 = group_sum<LPP>(a12);
+    a21 = group_sum<LPP>(a21);
+    a22 = group_sum<LPP>(a22);
+    if (active && sub == 0) {
+        const Mat2 B = kgc_from_A(a11, a12, a21, a22);
+        t.B[i] = make_double4(B.m11, B.m12, B.m21, B.m22);
+    }
+}
+
+// pass CD (see k_forces); TILE > 0: neighbour records come from the LDS tile (tile_ranges)
+struct FluidNb {
+    double2 p, v;
+    double4 a, B;
+};
+
+template <int LPP, int TILE>
+__global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+                                                     FluidTmp t, Walls w)
+{
+    constexpr int kSlots = TILE > 0 ? TILE : 1;
+    __shared__ double2 c_pos[kSlots], c_vel[kSlots];
+    __shared__ double4 c_a[kSlots], c_B[kSlots];
+    SPHX_PASS_INDEX();
+    const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const double2 vi = in_cap ? s.vel[i] : make_double2(0.0, 0.0);
+    const double4 ai = in_cap ? t.a[i] : make_double4(1.0, 0.0, 0.0, 0.0);
+    const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
+    const double mi = in_cap ? s.mass[i] : 1.0;
+    const int packed = t.nl_cnt[tid];
+    const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
+    const bool tracked = s.posb != nullptr;
+    const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
+    const double dt = clk->dt;
+    if (!clk->run[q]) return;
+    const int n_now = clk->n;
+    const bool active = i < n_now;
+    const int rows = active ? list_rows(packed) : 0, rows_fl = active ? list_fluid_rows(packed) : 0;
+    const double h = ph.kc.h, soft = 0.01 * h;
+    double ax = 0.0, ay = 0.0, ix = 0.0, iy = 0.0, px = 0.0, py = 0.0, d2 = 0.0;
+    const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
+    const double Voli = ai.x, p_i = ai.y, rhoh_i = ai.z;
+    const double b11i = Bi.x, b12i = Bi.y, b21i = Bi.z, b22i = Bi.w;
+
+    TileMap tm{0, 0, 0, 0, 0, 0};
+    if (TILE > 0) {
+        tm = tile_ranges<LPP>(g, s, blk, n_now, TILE);
+        for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
+            const int k = tm.index(sl);
+            c_pos[sl] = s.pos[k];
+            c_vel[sl] = s.vel[k];
+            c_a[sl] = t.a[k];
+            c_B[sl] = t.B[k];
+        }
+        __syncthreads();
+    }
+    auto fetch = [&](int k) {
+        FluidNb n;
+        if (TILE > 0) {  // (early return, not if/else: see k_kgc_w)
+            const int slot = tm.slot(k);
+            if (slot >= 0) {
+                n.p = c_pos[slot]; n.v = c_vel[slot]; n.a = c_a[slot]; n.B = c_B[slot];
+                return n;
+            }
+        }
+        n.p = s.pos[k]; n.v = s.vel[k]; n.a = t.a[k]; n.B = t.B[k];
+        return n;
+    };
+    auto fluid_pair = [&](const FluidNb &n, double dx) {
+#if SPHX_EXPERIMENT == 1   /* memory only */
+        ax += dx + n.p.y; ay += n.v.x + n.v.y; ix += n.a.x + n.a.y; iy += n.a.z; px += n.B.x + n.B.y; py += n.B.z + n.B.w;
+        return;
+#endif
+        const double dy = yi - n.p.y;
+        const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
+        const double ex = dx * inv_r, ey = dy * inv_r;
+        const double dWVj = spline_dW_sel(ph.kc, r) * n.a.x;
+        const double tx = (b11i + n.B.x) * ex + (b12i + n.B.y) * ey;
+        const double ty = (b21i + n.B.z) * ex + (b22i + n.B.w) * ey;
+        const double eBe = ex * tx + ey * ty;
+        // viscous
+        const double coeff = eBe * ph.mu * dWVj * rcp_nr(r + soft);
+        ax += coeff * (vxi - n.v.x);
+        ay += coeff * (vyi - n.v.y);
+        // transport
+        ix -= dWVj * tx;
+        iy -= dWVj * ty;
+        // pressure (Riemann-dissipated face pressure)
+        const double rho_bar = 0.5 * (rhoh_i + n.a.z);
+        const double un_l = vxi * ex + vyi * ey, un_r = n.v.x * ex + n.v.y * ey;
+        const double beta = riemann_beta(un_l, un_r, ph.c_f);
+        const double p_avg = 0.5 * (p_i + n.a.y);
+        const double p_star = p_avg + 0.5 * beta * rho_bar * (un_l - un_r);
+        const double p_face = 0.5 * (p_avg + p_star);
+        px -= (p_face * tx) * dWVj;
+        py -= (p_face * ty) * dWVj;
+    };
+#if SPHX_EXPERIMENT == 2   /* compute only: no gathers */
+    walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+        FluidNb n;
+        n.p = make_double2(xi - (double)(k & 7) * 1e-3 - 1e-4, yi - (double)(k & 3) * 1e-3);
+        n.v = make_double2(vxi * 0.9, vyi + 0.01); n.a = ai; n.B = Bi;
+        fluid_pair(n, xi - n.p.x);
+    });
+#else
+    if (__any(active && near_seam(g, xi)))
+        walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+            const FluidNb n = fetch(k);
+            fluid_pair(n, min_image(g, xi - n.p.x));
+        });
+    else
+        walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+            const FluidNb n = fetch(k);
+            fluid_pair(n, xi - n.p.x);
+        });
+#endif
+    // wall neighbours: viscous and transport now, pressure once force_prior is complete (p_wall needs it, :931-934)
+    walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
+        const double2 pj = w.pos[k];
+        const double4 wj = w.a[k];
+        const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
+        const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
+        const double ex = dx * inv_r, ey = dy * inv_r;
+        const double dWVj = spline_dW_sel(ph.kc, r) * wj.x;
+        const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
+        const double eBe = ex * tx + ey * ty;
+        const double coeff = 4.0 * eBe * ph.mu * dWVj * rcp_nr(r + soft);
+        ax += coeff * (vxi - wj.y);
+        ay += coeff * (vyi - wj.z);
+        ix -= 2.0 * dWVj * tx;
+        iy -= 2.0 * dWVj * ty;
+    });
+    ax = group_sum<LPP>(ax);
+    ay = group_sum<LPP>(ay);
+    ix = group_sum<LPP>(ix);
+    iy = group_sum<LPP>(iy);
+    const double fpx = ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
+    const double fpy = ay * Voli;
+    const double inv_m = rcp_nr(mi);
+    if (rows > rows_fl) {
+        const double acx = fpx * inv_m, acy = fpy * inv_m;
+        walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
+            const double2 pj = w.pos[k];
+            const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
+            const double ex = dx * inv_r, ey = dy * inv_r;
+            const double dWVj = spline_dW_sel(ph.kc, r) * w.a[k].x;
+            const double face = -(acx * ex + acy * ey);
+            const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
+            const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
+            px -= (p_i + p_wall) * dWVj * tx;
+            py -= (p_i + p_wall) * dWVj * ty;
+        });
+    }
+    px = group_sum<LPP>(px);
+    py = group_sum<LPP>(py);
+    if (active && sub == 0) {
+        const double fx = px * Voli, fy = py * Voli;
+        const double vxn = vxi + (fpx + fx) * inv_m * dt;
+        const double vyn = vyi + (fpy + fy) * inv_m * dt;
+        // transport limiter min(1, 100 |inc|^2 / h^2) (sph_physics_mex.c:702-710) with 1/h^2 multiplied in
+        const double lim = fmin(100.0 * (ix * ix + iy * iy) * (ph.kc.inv_h * ph.kc.inv_h), 1.0);
+        const double sx = ph.tc * h * h * lim * ix, sy = ph.tc * h * h * lim * iy;
+        double xo = xi + sx, yo = yi + sy;
+        xo += 0.5 * dt * vxi;
+        yo += 0.5 * dt * vyi;
+        xo += 0.5 * dt * vxn;
+        yo += 0.5 * dt * vyn;
+        if (tracked) {
+            const double ddx = min_image(g, xo - pb.x), ddy = yo - pb.y;
+            d2 = ddx * ddx + ddy * ddy;
+            if (d2 != d2) d2 = INFINITY;
+        }
+        // periodic wrap (SPH_Poiseuille.m:570-577): a step moves a particle by a tiny fraction of DL, so x - floor(x/DL) DL
+        // is x - DL, x + DL or x -- the same values without the division (a slab wraps when particles change owner)
+        if (g.periodic) xo = xo >= ph.DL ? xo - ph.DL : (xo < 0.0 ? xo + ph.DL : xo);
+        t.posn[i] = make_double2(xo, yo);
         t.veln[i] = make_double2(vxn, vyn);
         t.fp[i] = make_double2(fpx, fpy);
         t.f[i] = make_double2(fx, fy);
@@ -774,10 +1281,14 @@ __device__ __forceinline__ void continuity_tail(Clock *clk, int q, const Phys &p
 }
 
 // tail: 1 = the launch has one workgroup more than the pass needs; it runs continuity_tail
-template <int LPP>
+// WALK: the large-channel form of the walk (see the "_w" kernels): entries ahead, fluid / wall loops, fold hoisted
+template <int LPP, bool WALK, int TILE>
 __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
                                                        FluidSet s, FluidTmp t, Walls w, int do_hist, int tail)
 {
+    constexpr int kSlots = TILE > 0 ? TILE : 1;
+    __shared__ double2 c_pos[kSlots], c_vel[kSlots];
+    __shared__ double c_vol[kSlots];
     const int nb = (int)gridDim.x - tail;
     if (tail && (int)blockIdx.x == nb) {
         continuity_tail(clk, q, ph, t, nb);
@@ -789,13 +1300,14 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
     const bool in_cap = i < t.cap;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? t.veln[i] : make_double2(0.0, 0.0);
-    const int nn_all = t.nl_cnt[tid];
+    const int packed = t.nl_cnt[tid];
+    const int nn_all = list_rows(packed);
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
     // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
     // (rows 2 and 3 only where lanes own that many: few lanes per particle)
-    const int e_row2 = LPP <= 8 ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
-    const int e_row3 = LPP <= 8 ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
+    const int e_row2 = (!WALK && LPP <= 8) ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
+    const int e_row3 = (!WALK && LPP <= 8) ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     const bool lead = in_cap && sub == 0;
     const double rhoh_i = lead ? t.a[i].z : 0.0;
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
@@ -804,7 +1316,49 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
     const bool active = i < clk->n;
     double rate = 0.0, v2 = 0.0;
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
-    if (active) {
+    if (WALK) {
+        const int rows = active ? nn_all : 0, rows_fl = active ? list_fluid_rows(packed) : 0;
+        TileMap tm{0, 0, 0, 0, 0, 0};
+        if (TILE > 0) {
+            tm = tile_ranges<LPP>(g, s, blk, clk->n, TILE);
+            for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
+                const int k = tm.index(sl);
+                c_pos[sl] = s.pos[k];
+                c_vel[sl] = t.veln[k];
+                c_vol[sl] = t.vol[k];
+            }
+            __syncthreads();
+        }
+        auto fetch = [&](int k, double2 &pj, double2 &vj, double &Volj) {
+            if (TILE > 0) {  // (early return, not if/else: see k_kgc_w)
+                const int slot = tm.slot(k);
+                if (slot >= 0) { pj = c_pos[slot]; vj = c_vel[slot]; Volj = c_vol[slot]; return; }
+            }
+            pj = s.pos[k]; vj = t.veln[k]; Volj = t.vol[k];
+        };
+        auto term = [&](double dx, double dy, double ujx, double ujy, double Volj) {
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
+            const double ex = dx * inv_r, ey = dy * inv_r;
+            rate += ((vxi - ujx) * ex + (vyi - ujy) * ey) * spline_dW_sel(ph.kc, r) * Volj;
+        };
+        if (__any(active && near_seam(g, xi)))
+            walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+                double2 pj, vj; double Volj;
+                fetch(k, pj, vj, Volj);
+                term(min_image(g, xi - pj.x), yi - pj.y, vj.x, vj.y, Volj);
+            });
+        else
+            walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+                double2 pj, vj; double Volj;
+                fetch(k, pj, vj, Volj);
+                term(xi - pj.x, yi - pj.y, vj.x, vj.y, Volj);
+            });
+        walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
+            const double2 pj = w.pos[k];
+            const double4 wj = w.a[k];  // {Vol, vx, vy, -}; the wall presents its velocity mirrored through the particle's
+            term(min_image(g, xi - pj.x), yi - pj.y, 2.0 * wj.y - vxi, 2.0 * wj.z - vyi, wj.x);
+        });
+    } else if (active) {
         for (int m = 0; m < nn_all; ++m) {
             const int e = m == 0 ? e_row0 : (m == 1 ? e_row1 : (LPP <= 8 && m == 2 ? e_row2 : (LPP <= 8 && m == 3 ? e_row3 : t.nl_idx[(size_t)m * t.nl_stride + tid])));
             const bool wall = (e & kWallBit) != 0;

@@ -144,6 +144,9 @@ struct sphx_ctx {
     // Dynamic re-binning (large channels): the device decides when to re-bin, every step carries the (self-skipping)
     // re-binning kernels, the layout is rebuilt in place -> lay stays 0, only the state parity alternates
     bool dyn = false;
+    bool walk_kernels = false;   // lanes_per_particle <= 8: passes B, CD, E run their large-channel ("_w") forms
+    bool lds_tiles = false;      // ... and the force pass stages its tile's neighbourhood in LDS
+    bool lds_tiles_be = false;   // ... KGC and continuity too (2 lanes per particle, channel larger than the Infinity Cache)
     bool tail_clock = false;     // move steps carry their clock update in a tail workgroup of pass E (small channels)
 
     FluidSet view(int q, int l)
@@ -239,17 +242,43 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
     if (!only || only == 1) {
         if (dmode == 0) launch(c, "k_density", k_density<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
         else if (dmode == 1) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
-        else if (dmode == 2) launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
-        else {  // dynamic: both, each skipping itself according to the clock's `fresh`
-            launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, 1);
-            launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, 0);
+        else {
+            // dmode 2: walk the superset list; 3 (dynamic contexts): build and walk, each skipping itself according to the
+            // clock's `fresh`
+            const int cond = dmode == 2 ? -1 : 0;
+            if (dmode == 3) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, 1);
+            bool walk_w = false;
+            if constexpr (LPP <= 8) walk_w = c->walk_kernels;
+            if (!walk_w) launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+            else if constexpr (LPP <= 8) launch(c, "k_density_walk", k_density_w<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
         }
     }
-    if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
-    if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
-    if (!only || only == 4)
-        launch(c, tail ? "k_continuity_clock" : "k_continuity", k_continuity<LPP>, dim3(c->n_blocks_particles + tail), bp,
-               c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
+    // large channels (few lanes per particle) run the "_w" forms of passes B, CD and E, see sphx_kernels.hpp
+    bool walk = false;
+    if constexpr (LPP <= 8) walk = c->walk_kernels;
+    const dim3 ge(c->n_blocks_particles + tail);
+    const char *name_e = tail ? "k_continuity_clock" : "k_continuity";
+    if (!walk) {
+        if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        if (!only || only == 4)
+            launch(c, name_e, k_continuity<LPP, false, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
+    } else if constexpr (LPP <= 8) {
+        // LDS tiles (tile_ranges): the force pass always; KGC and continuity where measured to pay (lds_tiles_be)
+        constexpr int T = tile_slots(LPP);
+        if (!only || only == 2) {
+            if (c->lds_tiles_be) launch(c, "k_kgc", k_kgc_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+            else launch(c, "k_kgc", k_kgc_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        }
+        if (!only || only == 3) {
+            if (c->lds_tiles) launch(c, "k_forces", k_forces_w<LPP, (LPP <= 2 ? 320 : T)>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+            else launch(c, "k_forces", k_forces_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        }
+        if (!only || only == 4) {
+            if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
+            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
+        }
+    }
 }
 
 void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0, int dmode = 0,
@@ -485,7 +514,11 @@ void enqueue_slots(sphx_ctx *c, int64_t slots, bool exact_tail, bool capture_onl
         }
         if (n > 0) {
             hipGraphExec_t exec = get_graph(c, c->cur, c->lay, c->pos, n);
-            if (!capture_only) {
+            if (capture_only) {
+                // have the executable graph resident on the device before its first replay (otherwise that replay pays
+                // for the upload); optional -- a runtime that cannot do it reports an error, which is dropped
+                if (hipGraphUpload(exec, c->stream) != hipSuccess) (void)hipGetLastError();
+            } else {
                 SPHX_HIP(hipGraphLaunch(exec, c->stream));
                 c->slots_replayed += n;
             }
@@ -603,7 +636,10 @@ int pick_lpp(int nf)
 {
     // enough lanes to put ~4 waves on each of the 1024 SIMDs; 4..32 lanes per particle (measured: with the
     // balanced neighbour list 4 lanes beat 1-2 even at 6 M particles, 32 beat 16 at 5 k)
+    // Round 2 (entries ahead, LDS tile in the force pass): 2 lanes beat 4 from 0.5 M particles (189 vs 193 us/step) and
+    // clearly at 6 M (2195 vs 2416); at 65 k particles 4 lanes keep more waves in flight (51 vs 60 us/step).
     const long target = 256L * 4 * 4 * 64;
+    if (nf >= 250000) return 2;
     int lpp = 4;
     while (lpp < 32 && (long)nf * lpp * 2 <= target) lpp *= 2;
     return lpp;
@@ -805,6 +841,9 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
     check_lpp(c->lpp);
+    c->walk_kernels = c->lpp <= 8 && !std::getenv("SPHX_NO_WALK_KERNELS");  // (the environment switches are for A/B runs)
+    c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");
+    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && c->nf >= 2000000;
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 40;  // measured at C2: 10 -> 25.4, 40 -> 25.1, 80 -> 24.8 us/step
     if (c->spg & 1) c->spg += 1;
 
@@ -1393,6 +1432,9 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(n_local);
     check_lpp(c->lpp);
+    c->walk_kernels = c->lpp <= 8 && !std::getenv("SPHX_NO_WALK_KERNELS");  // (the environment switches are for A/B runs)
+    c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");
+    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_local >= 2000000;
     c->spg = 2;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else SPHX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

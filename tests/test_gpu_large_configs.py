@@ -1,6 +1,6 @@
 """-m gpu: BASELINE.json configs[2..4] (C3 dp 0.01/DL 6, C4 dp 0.005/DL 12, C5 dp 0.002/DL 24) on the DEFAULT
 context against the oracle's time loop -- the code paths the small cases never reach: automatic lanes per
-particle (4), the multi-block cell scan (> 8 192 cells: k_scan_tiles / k_scan_add), k_max_tiles (> 16 k
+particle (4 / 2 / 2) with the large-channel kernels (entries ahead, fluid / wall loops, LDS tiles), the multi-block cell scan (> 8 192 cells: k_scan_tiles / k_scan_add), k_max_tiles (> 16 k
 workgroups), the grid-stride re-binning kernels, size_t index products and, from 10^6 fluid particles, the
 device-decided ("dynamic") re-binning with its in-place reorder (k_copyback).
 
@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
 #        name   dp     DL    steps  expected policy
 CASES = [("C3", 0.01, 6.0, 7, dict(lpp=4, dynamic=False, big_scan=False)),
-         ("C4", 0.005, 12.0, 6, dict(lpp=4, dynamic=False, big_scan=True)),
-         ("C5", 0.002, 24.0, 6, dict(lpp=4, dynamic=True, big_scan=True))]
+         ("C4", 0.005, 12.0, 6, dict(lpp=2, dynamic=False, big_scan=True)),
+         ("C5", 0.002, 24.0, 6, dict(lpp=2, dynamic=True, big_scan=True))]
 
 
 def _compare(name, prm, parts, n_steps, capi, oracle, expect, **ctx_kw):
@@ -63,7 +63,7 @@ def test_c4_dynamic_rebinning_matches_oracle(cfgmod, geom, capi, oracle):
     """0.5 M particles with the device-decided re-binning forced on and a skin small enough that the drift bound
     (not the schedule) triggers re-binnings inside the window: k_bin + the multi-block scan + k_copyback."""
     prm, parts = make_case(cfgmod, geom, dp=0.005, DL=12.0, jitter=0.2, seed=5, developed=True)
-    pol = _compare("C4dyn", prm, parts, 6, capi, oracle, dict(lpp=4, big_scan=True), dynamic_rebin=1, skin_h=0.05)
+    pol = _compare("C4dyn", prm, parts, 6, capi, oracle, dict(lpp=2, big_scan=True), dynamic_rebin=1, skin_h=0.05)
     assert pol["forced_rebuilds"] >= 1, pol  # re-binnings triggered by the drift bound
 
 
