@@ -236,6 +236,8 @@ int sphx_ctx_info(sphx_ctx *ctx, int *n_fluid, int *n_wall, int *n_cell_x, int *
  *    The reference has no counterpart (single process).  One step is
  *        sphx_slab_compute -> {exchange two messages with the ring neighbours, all-reduce max|v|}
  *        -> sphx_slab_finish
+ *    either driven by the caller with its own transport (the three calls below) or by the library's native loop
+ *    over RCCL (sphx_slab_run).
  *    All *_dev pointers are DEVICE pointers (e.g. torch tensors) and every call is asynchronous on the
  *    context's stream (hip_stream of sphx_slab_create, or an internal one when NULL).
  * ---------------------------------------------------------------------------------------------- */
@@ -263,6 +265,19 @@ int sphx_slab_compute(sphx_ctx *ctx, double *send_left_dev, double *send_right_d
  * update the clock and rebuild the cell grid. */
 int sphx_slab_finish(sphx_ctx *ctx, const double *recv_left_dev, const double *recv_right_dev,
                      const double *vmax_global_dev);
+/* Native step loop.  sphx_slab_run enqueues n_steps whole steps (compute -> two sends + two receives with the ring
+ * neighbours and an 8-byte max all-reduce through RCCL -> finish) on the context's stream, in library-owned message
+ * buffers; nothing of the host language runs between steps.  One context per process (one process per GPU): rank 0
+ * makes an id with sphx_comm_unique_id (128 bytes), the launcher carries it to the other ranks (torch.distributed
+ * broadcast, MPI, a file ...), every rank joins with sphx_slab_comm_init.  librccl is loaded at that moment.
+ * sphx_slab_group_run: all slabs of the ring in ONE process on one device -- the same loop with device-to-device
+ * copies as the transport (tests and rehearsals on a one-GPU box).  Both return without waiting; sphx_slab_sync
+ * waits and reports. */
+int sphx_comm_unique_id(void *id_bytes, int capacity);
+int sphx_slab_comm_init(sphx_ctx *ctx, const void *id_bytes);
+int sphx_slab_comm_destroy(sphx_ctx *ctx);
+int sphx_slab_run(sphx_ctx *ctx, double t_target, int64_t n_steps);
+int sphx_slab_group_run(sphx_ctx **ctxs, int n_ranks, double t_target, int64_t n_steps);
 /* Wait for the stream; fails if a step was enqueued after the loop had stopped or a buffer overflowed. */
 int sphx_slab_sync(sphx_ctx *ctx, sphx_status *status);
 /* Host copy of the slab's current particles (owned + halo copies); owned[i] = 1 for owned ones. */

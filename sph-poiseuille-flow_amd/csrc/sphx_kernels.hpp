@@ -1648,6 +1648,13 @@ __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int
     }
 }
 
+// both step-slot flags off: whatever is enqueued next returns at once (sphx_ctx_prepare_steps warms graphs this way)
+__global__ void k_disarm(Clock *clk)
+{
+    clk->run[0] = 0;
+    clk->run[1] = 0;
+}
+
 __global__ void k_rebinned(Clock *clk)
 {
     clk->drift = 0.0;

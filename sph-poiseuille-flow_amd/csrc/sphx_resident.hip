@@ -2,6 +2,9 @@
 // context creation (cell grid build on device), the step loop as hipGraph replays, download, monitors,
 // MEX-convention pair-list emission, per-kernel HIP-event timing, and the x-slab (multi-GPU) entry
 // points.  The kernels are in sphx_kernels.hpp.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is loaded at run time (see Rccl), libsphx does not link it
+
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -138,6 +141,10 @@ struct sphx_ctx {
     int64_t slab_steps_enqueued = 0, slab_step0 = 0;
     // optional (SPHX_SLAB_GRAPH=1): each half-step captured once per parity (and per buffer set) and replayed;
     // slower than plain launches for graphs this small, see slab_half
+    // native step loop (sphx_slab_run / sphx_slab_group_run): library-owned message buffers, RCCL communicator
+    DevBuf<double> msg_sl, msg_sr, msg_rl, msg_rr, vmax_l, vmax_g;
+    ncclComm_t comm = nullptr;
+    hipEvent_t ev_computed = nullptr, ev_received = nullptr;  // single-process ring: cross-stream ordering
     hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
     const void *slab_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
@@ -174,6 +181,8 @@ struct sphx_ctx {
         for (auto &h : slab_graph) for (auto &e : h) if (e) (void)hipGraphExecDestroy(e);
         timer.collect();
         timer.drop_graph_events();
+        if (ev_computed) (void)hipEventDestroy(ev_computed);
+        if (ev_received) (void)hipEventDestroy(ev_received);
         if (h_clock) (void)hipHostFree(h_clock);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
@@ -515,9 +524,11 @@ void enqueue_slots(sphx_ctx *c, int64_t slots, bool exact_tail, bool capture_onl
         if (n > 0) {
             hipGraphExec_t exec = get_graph(c, c->cur, c->lay, c->pos, n);
             if (capture_only) {
-                // have the executable graph resident on the device before its first replay (otherwise that replay pays
-                // for the upload); optional -- a runtime that cannot do it reports an error, which is dropped
-                if (hipGraphUpload(exec, c->stream) != hipSuccess) (void)hipGetLastError();
+                // First replays are slow (~4 us per step slot on ROCm 7.2: the executable graph is set up on the device
+                // at its first launch, hipGraphUpload does not take that over): replay it once now with the clock
+                // disarmed (k_disarm, see sphx_ctx_prepare_steps), so every kernel of every slot returns at once and
+                // nothing changes.
+                SPHX_HIP(hipGraphLaunch(exec, c->stream));
             } else {
                 SPHX_HIP(hipGraphLaunch(exec, c->stream));
                 c->slots_replayed += n;
@@ -972,6 +983,7 @@ SPHX_EXPORT void sphx_ctx_destroy(sphx_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)sphx_slab_comm_destroy(ctx);
     if (g_fetch_src == ctx) g_fetch_src = nullptr;
     delete ctx;
 }
@@ -1044,7 +1056,9 @@ SPHX_EXPORT int sphx_ctx_prepare_steps(sphx_ctx *c, int64_t n_steps)
     require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
     read_clock(c);  // the phase the next batch starts from
     if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
+    hipLaunchKernelGGL(k_disarm, dim3(1), dim3(1), 0, c->stream, c->clock.get());  // (every batch re-arms with k_prepare)
     enqueue_slots(c, n_steps, true, true);
+    SPHX_HIP(hipStreamSynchronize(c->stream));
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -1558,11 +1572,11 @@ SPHX_EXPORT int sphx_slab_prepare(sphx_ctx *c, double t_target, int64_t max_step
     SPHX_CATCH
 }
 
-SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *send_right_dev, double *vmax_local_dev)
+namespace {
+
+// first half of a slab step on the context's stream: the four neighbour passes, pack, seal + local max |v|
+void slab_compute_impl(sphx_ctx *c, double *send_left_dev, double *send_right_dev, double *vmax_local_dev)
 {
-    SPHX_TRY
-    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
-    require(send_left_dev && send_right_dev && vmax_local_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
     const int q = c->cur;
     const Clock *clk = c->clock.get();
     auto body = [&]() {
@@ -1577,19 +1591,14 @@ SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *se
     const void *key[3] = {send_left_dev, send_right_dev, vmax_local_dev};
     slab_half(c, 0, q, key, body);
     SPHX_HIP(hipGetLastError());
-    return SPHX_OK;
-    SPHX_CATCH
 }
 
-SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const double *recv_right_dev,
-                                 const double *vmax_global_dev)
+// second half: unpack the received messages, clock update with the global max |v|, cell rebuild
+void slab_finish_impl(sphx_ctx *c, const double *recv_left_dev, const double *recv_right_dev, const double *vmax_global_dev)
 {
-    SPHX_TRY
-    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
-    require(recv_left_dev && recv_right_dev && vmax_global_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
     const int q = c->cur;
     Clock *clk = c->clock.get();
-    const dim3 g1(c->n_blocks_flat), bp(kBlock);
+    const dim3 bp(kBlock);
     auto body = [&]() {
         // kept particles were binned by the pack kernel, the received ones are binned here
         launch(c, "k_slab_unpack", k_slab_unpack, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), bp, (const Clock *)clk, q,
@@ -1620,6 +1629,242 @@ SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const
     SPHX_HIP(hipGetLastError());
     c->cur ^= 1;
     c->slab_steps_enqueued += 1;
+}
+
+}  // namespace
+
+SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *send_right_dev, double *vmax_local_dev)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    require(send_left_dev && send_right_dev && vmax_local_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
+    slab_compute_impl(c, send_left_dev, send_right_dev, vmax_local_dev);
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const double *recv_right_dev,
+                                 const double *vmax_global_dev)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    require(recv_left_dev && recv_right_dev && vmax_global_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
+    slab_finish_impl(c, recv_left_dev, recv_right_dev, vmax_global_dev);
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+// =================================================================================================
+// Native step loop of the slabs: everything a step needs is enqueued from here, no host language in the loop.
+//   sphx_slab_run        one context per process (one process per GPU): messages and the max all-reduce go through
+//                        RCCL on the context's stream -- two sends + two receives in one group per step (ring
+//                        neighbours: direct xGMI hops) and one 8-byte all-reduce;
+//   sphx_slab_group_run  all slabs of the ring live in one process on one device (tests, rehearsals on a one-GPU box):
+//                        the same loop with device-to-device copies as the transport and events for the ordering.
+// librccl is loaded when the first communicator is made (dlopen: PyTorch carries its own copy of the library and the two
+// must not be linked into one image twice), so a box without RCCL can still run everything single-GPU.
+// =================================================================================================
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+
+    static Rccl &get()
+    {
+        static Rccl r;
+        if (r.lib) return r;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", std::string("cannot load librccl: ") + dlerror());
+        auto sym = [&](const char *n) {
+            void *p = dlsym(r.lib, n);
+            if (!p) throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", std::string("librccl lacks ") + n);
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        return r;
+    }
+    void check(ncclResult_t e, const char *what)
+    {
+        if (e != ncclSuccess) throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", std::string(what) + ": " + GetErrorString(e));
+    }
+};
+
+void slab_native_buffers(sphx_ctx *c)
+{
+    if (c->msg_sl.get()) return;
+    const size_t n = 1 + 7 * (size_t)c->msg_cap;
+    c->msg_sl.alloc(n); c->msg_sr.alloc(n); c->msg_rl.alloc(n); c->msg_rr.alloc(n);
+    c->vmax_l.alloc(1); c->vmax_g.alloc(1);
+    for (DevBuf<double> *b : {&c->msg_sl, &c->msg_sr, &c->msg_rl, &c->msg_rr, &c->vmax_l, &c->vmax_g}) b->zero(c->stream);
+}
+
+struct PtrList {
+    const double *p[16];
+};
+// max of one double per rank (single-process ring: stands in for the all-reduce)
+__global__ void k_max_of(int n, PtrList src, double *out)
+{
+    double m = src.p[0][0];
+    for (int k = 1; k < n; ++k) m = fmax(m, src.p[k][0]);
+    *out = m;
+}
+
+}  // namespace
+
+SPHX_EXPORT int sphx_comm_unique_id(void *id_bytes, int capacity)
+{
+    SPHX_TRY
+    require(id_bytes != nullptr && capacity >= NCCL_UNIQUE_ID_BYTES, "SPHX:Slab:rccl", "id buffer must hold 128 bytes");
+    ncclUniqueId id;
+    Rccl &R = Rccl::get();
+    R.check(R.GetUniqueId(&id), "ncclGetUniqueId");
+    std::memcpy(id_bytes, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_slab_comm_init(sphx_ctx *c, const void *id_bytes)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab && id_bytes != nullptr, "SPHX:Slab:ctx", "not a slab context");
+    require(c->comm == nullptr, "SPHX:Slab:rccl", "communicator already initialised");
+    ncclUniqueId id;
+    std::memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
+    Rccl &R = Rccl::get();
+    R.check(R.CommInitRank(&c->comm, c->n_ranks, id, c->rank), "ncclCommInitRank");
+    slab_native_buffers(c);
+    SPHX_HIP(hipStreamSynchronize(c->stream));
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_slab_comm_destroy(sphx_ctx *c)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    if (c->comm) {
+        SPHX_HIP(hipStreamSynchronize(c->stream));
+        Rccl &R = Rccl::get();
+        R.check(R.CommDestroy(c->comm), "ncclCommDestroy");
+        c->comm = nullptr;
+    }
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    require(c->comm != nullptr, "SPHX:Slab:rccl", "sphx_slab_comm_init first");
+    require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
+    Rccl &R = Rccl::get();
+    hipStream_t st = c->stream;
+    const int left = (c->rank + c->n_ranks - 1) % c->n_ranks, right = (c->rank + 1) % c->n_ranks;
+    const size_t n_msg = 1 + 7 * (size_t)c->msg_cap;
+    double *sl = c->msg_sl.get(), *sr = c->msg_sr.get(), *rl = c->msg_rl.get(), *rr = c->msg_rr.get();
+    double *vl = c->vmax_l.get(), *vg = c->vmax_g.get();
+    // arm the clock with the global max |v| of the current state
+    const FluidSet fs = c->view(c->cur, c->cur);
+    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, st, c->clock.get(), c->grid, (const double2 *)fs.pos,
+                       (const double2 *)fs.vel, vl);
+    R.check(R.AllReduce(vl, vg, 1, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, st, c->clock.get(), c->phys, t_target, (long long)n_steps, c->cur,
+                       (const double *)vg);
+    for (int64_t k = 0; k < n_steps; ++k) {
+        slab_compute_impl(c, sl, sr, vl);
+        R.check(R.AllReduce(vl, vg, 1, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
+        // my left message is my left neighbour's "from the right" message and vice versa; with two ranks both go to
+        // the same peer, which posts its receives in the order the sends are posted here
+        R.check(R.GroupStart(), "ncclGroupStart");
+        R.check(R.Send(sl, n_msg, ncclDouble, left, c->comm, st), "ncclSend");
+        R.check(R.Send(sr, n_msg, ncclDouble, right, c->comm, st), "ncclSend");
+        R.check(R.Recv(rr, n_msg, ncclDouble, right, c->comm, st), "ncclRecv");
+        R.check(R.Recv(rl, n_msg, ncclDouble, left, c->comm, st), "ncclRecv");
+        R.check(R.GroupEnd(), "ncclGroupEnd");
+        slab_finish_impl(c, rl, rr, vg);
+    }
+    SPHX_HIP(hipGetLastError());
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int64_t n_steps)
+{
+    SPHX_TRY
+    require(ctxs != nullptr && n >= 2 && n <= 16, "SPHX:Slab:group", "a ring needs 2..16 slab contexts");
+    require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
+    PtrList vls{};
+    for (int r = 0; r < n; ++r) {
+        sphx_ctx *c = ctxs[r];
+        require(c != nullptr && c->is_slab && c->rank == r && c->n_ranks == n, "SPHX:Slab:group",
+                "ctxs[r] must be slab r of an n-slab ring");
+        slab_native_buffers(c);
+        if (!c->ev_computed) {
+            SPHX_HIP(hipEventCreateWithFlags(&c->ev_computed, hipEventDisableTiming));
+            SPHX_HIP(hipEventCreateWithFlags(&c->ev_received, hipEventDisableTiming));
+        }
+        vls.p[r] = c->vmax_l.get();
+    }
+    // every rank: local max |v| -> (all ranks ready) -> global max -> arm
+    for (int r = 0; r < n; ++r) {
+        sphx_ctx *c = ctxs[r];
+        const FluidSet fs = c->view(c->cur, c->cur);
+        hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, c->stream, c->clock.get(), c->grid, (const double2 *)fs.pos,
+                           (const double2 *)fs.vel, c->vmax_l.get());
+        SPHX_HIP(hipEventRecord(c->ev_computed, c->stream));
+    }
+    for (int r = 0; r < n; ++r) {
+        sphx_ctx *c = ctxs[r];
+        for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(c->stream, ctxs[o]->ev_computed, 0));
+        hipLaunchKernelGGL(k_max_of, dim3(1), dim3(1), 0, c->stream, n, vls, c->vmax_g.get());
+        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target, (long long)n_steps, c->cur,
+                           (const double *)c->vmax_g.get());
+        SPHX_HIP(hipEventRecord(c->ev_received, c->stream));
+    }
+    const size_t msg_bytes = (1 + 7 * (size_t)ctxs[0]->msg_cap) * sizeof(double);
+    for (int r = 1; r < n; ++r)
+        require(ctxs[r]->msg_cap == ctxs[0]->msg_cap, "SPHX:Slab:group", "slabs of one ring share the message capacity");
+    for (int64_t k = 0; k < n_steps; ++k) {
+        for (int r = 0; r < n; ++r) {
+            sphx_ctx *c = ctxs[r];
+            // the others must have consumed my previous messages and my previous local max before I overwrite them
+            for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(c->stream, ctxs[o]->ev_received, 0));
+            slab_compute_impl(c, c->msg_sl.get(), c->msg_sr.get(), c->vmax_l.get());
+            SPHX_HIP(hipEventRecord(c->ev_computed, c->stream));
+        }
+        for (int r = 0; r < n; ++r) {
+            sphx_ctx *c = ctxs[r];
+            sphx_ctx *L = ctxs[(r + n - 1) % n], *Rr = ctxs[(r + 1) % n];
+            for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(c->stream, ctxs[o]->ev_computed, 0));
+            SPHX_HIP(hipMemcpyAsync(c->msg_rl.get(), L->msg_sr.get(), msg_bytes, hipMemcpyDeviceToDevice, c->stream));
+            SPHX_HIP(hipMemcpyAsync(c->msg_rr.get(), Rr->msg_sl.get(), msg_bytes, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_max_of, dim3(1), dim3(1), 0, c->stream, n, vls, c->vmax_g.get());
+            SPHX_HIP(hipEventRecord(c->ev_received, c->stream));
+            slab_finish_impl(c, c->msg_rl.get(), c->msg_rr.get(), c->vmax_g.get());
+        }
+    }
+    SPHX_HIP(hipGetLastError());
     return SPHX_OK;
     SPHX_CATCH
 }

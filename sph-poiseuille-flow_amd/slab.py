@@ -111,15 +111,19 @@ class HipSlabEngine:
     """libsphx slab context of one rank; device buffers are torch tensors so RCCL can move them."""
 
     def __init__(self, prm, parts, rank, world, device, lanes_per_particle=0, halo_cols=HALO_COLS, t_end=None,
-                 pos=None, vel=None, drho_dt=None):
-        import torch
+                 pos=None, vel=None, drho_dt=None, native=False):
+        """native=True: the context runs on a stream of its own and keeps its message buffers inside the library (the
+        native loop: run() over RCCL, or group_run() for a ring living in one process); no torch tensors involved."""
         from . import capi
-        self.capi, self.torch = capi, torch
-        self.rank, self.world = rank, world
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
+        self.capi = capi
+        self.rank, self.world, self.native = rank, world, native
         capi.set_device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        if not native:
+            import torch
+            self.torch = torch
+            self.device = torch.device("cuda", device)
+            torch.cuda.set_device(self.device)
+            self.stream = torch.cuda.Stream(device=self.device)
         self.params = capi.make_params(prm, t_end, None, lanes_per_particle, 0)
         nf, nt = parts["n_fluid"], parts["n_total"]
         f = capi.f64
@@ -131,14 +135,17 @@ class HipSlabEngine:
         capi.check(capi.lib().sphx_slab_create(C.byref(self._h), C.byref(self.params), C.c_int(nf), C.c_int(nt),
                                                capi.ptr(pos), capi.ptr(vel), capi.ptr(drho), capi.ptr(mass), capi.ptr(wv),
                                                C.c_double(0.0), C.c_int64(0), C.c_int(rank), C.c_int(world),
-                                               C.c_int(halo_cols), C.c_void_p(self.stream.cuda_stream)))
+                                               C.c_int(halo_cols),
+                                               C.c_void_p(None if native else self.stream.cuda_stream)))
+        self.n_total_global = nt
+        if native:
+            return
         lay = self.layout()
         n = lay["msg_doubles"]
         with torch.cuda.stream(self.stream):
             mk = lambda: torch.zeros(n, dtype=torch.float64, device=self.device)
             self.send_l, self.send_r, self.recv_l, self.recv_r = mk(), mk(), mk(), mk()
             self.vmax = torch.zeros(1, dtype=torch.float64, device=self.device)
-        self.n_total_global = nt
 
     def _p(self, t):
         return C.cast(C.c_void_p(t.data_ptr()), C.POINTER(C.c_double))
@@ -181,6 +188,27 @@ class HipSlabEngine:
 
     def stream_ctx(self):
         return self.torch.cuda.stream(self.stream)
+
+    # ---- native loop --------------------------------------------------------------------------------
+    @staticmethod
+    def unique_id(capi) -> bytes:
+        buf = C.create_string_buffer(128)
+        capi.check(capi.lib().sphx_comm_unique_id(buf, C.c_int(128)))
+        return buf.raw
+
+    def comm_init(self, id_bytes: bytes):
+        self.capi.check(self.capi.lib().sphx_slab_comm_init(self._h, C.c_char_p(id_bytes)))
+
+    def run(self, n_steps, t_target=1e300):
+        """n_steps whole steps over RCCL, enqueued natively; returns at once (sync() waits)."""
+        self.capi.check(self.capi.lib().sphx_slab_run(self._h, C.c_double(t_target), C.c_int64(n_steps)))
+
+    @staticmethod
+    def group_run(engines, n_steps, t_target=1e300):
+        """The ring `engines` (all in this process, one device) takes n_steps steps with device-to-device copies."""
+        capi = engines[0].capi
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        capi.check(capi.lib().sphx_slab_group_run(arr, C.c_int(len(engines)), C.c_double(t_target), C.c_int64(n_steps)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -271,65 +299,91 @@ def dt_upper_bound(prm) -> float:
 
 
 def bench_main(args, rank, world, local_rank):
-    """bench.py --gpus N (N > 1): weak scaling of the headline configuration -- every GPU holds one
-    dp = 0.025, DL = 3 channel section (5 760 particles), the N-GPU channel is DL = 3 N long."""
+    """bench.py --gpus N (N > 1).  Headline: weak scaling of the headline configuration -- every GPU holds one
+    dp = 0.025, DL = 3 channel section (5 760 particles), the N-GPU channel is DL = 3 N long.  `aux`: the
+    6.1 M-particle channel (C5) cut into N slabs -- the strong-scaling case the north star quotes."""
     import importlib
     import torch
     import torch.distributed as dist
     pkg = importlib.import_module(__package__)
-    cfg, geo = pkg.config, pkg.geometry
+    cfg, geo, capi = pkg.config, pkg.geometry, pkg.capi
     backend = os.environ.get("SPHX_DIST_BACKEND", "nccl")  # "gloo": rehearsal with ranks sharing one GPU
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend)
-    name = args.workload or "C2"
+    # the library's own loop over RCCL unless told otherwise (or unless the ranks cannot have a GPU each)
+    native = dist.get_backend() == "nccl" and os.environ.get("SPHX_SLAB_LOOP", "native") == "native"
     workloads = {"C1": dict(dp=0.04, DL=3.0), "C2": dict(dp=0.025, DL=3.0), "C3": dict(dp=0.01, DL=6.0),
                  "C4": dict(dp=0.005, DL=12.0), "C5": dict(dp=0.002, DL=24.0)}
-    strong = name.endswith(":strong")
-    base = dict(workloads[name.split(":")[0]])
-    kw = dict(base) if strong else dict(base, DL=base["DL"] * world)
-    prm = cfg.params_from_values(end_time=1e9, **kw)
-    parts = geo.init_particles(prm)
-    if args.lattice:
-        pos, vel, start = parts["pos"], parts["vel"], "lattice at rest"
-    else:
-        pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
-        start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
-    eng = HipSlabEngine(prm, parts, rank, world, local_rank, lanes_per_particle=args.lpp, t_end=1e9, pos=pos, vel=vel)
-    drv = SlabDriver(eng, RingExchange(rank, world))
-    if args.warmup > 0:
-        drv.run_steps(args.warmup)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    st = drv.run_steps(args.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    seconds = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
-                           device=eng.device if backend == "nccl" else "cpu")
-    dist.all_reduce(seconds, op=dist.ReduceOp.MAX)
-    seconds = float(seconds.item())
-    nt = parts["n_total"]
-    lay = eng.layout()
+
+    def run_case(name, steps, warmup):
+        strong = name.endswith(":strong")
+        base = dict(workloads[name.split(":")[0]])
+        kw = dict(base) if strong else dict(base, DL=base["DL"] * world)
+        prm = cfg.params_from_values(end_time=1e9, **kw)
+        parts = geo.init_particles(prm)
+        if args.lattice:
+            pos, vel, start = parts["pos"], parts["vel"], "lattice at rest"
+        else:
+            pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
+            start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
+        eng = HipSlabEngine(prm, parts, rank, world, local_rank, lanes_per_particle=args.lpp, t_end=1e9, pos=pos, vel=vel,
+                            native=native)
+        if native:
+            ident = [HipSlabEngine.unique_id(capi) if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            eng.comm_init(ident[0])
+            run = lambda n: (eng.run(n), eng.sync())[1]
+        else:
+            drv = SlabDriver(eng, RingExchange(rank, world))
+            run = drv.run_steps
+        if warmup > 0:
+            run(warmup)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = run(steps)
+        torch.cuda.synchronize()
+        dist.barrier()
+        seconds = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                               device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(seconds, op=dist.ReduceOp.MAX)
+        seconds = float(seconds.item())
+        nt, lay = parts["n_total"], eng.layout()
+        eng.close()
+        alg = (528 * parts["n_fluid"] + 120 * parts["n_wall"]) * steps / seconds / 1e9
+        loop = ("native step loop in libsphx over RCCL: ncclSend/ncclRecv ring + one 8-byte ncclAllReduce(max) per step"
+                if native else f"Python step loop over torch.distributed[{dist.get_backend()}]"
+                               + (" (messages staged through host memory)" if dist.get_backend() != "nccl" else ""))
+        return dict(value=nt * steps / seconds, ms_per_step=1e3 * seconds / steps, steps=steps, warmup=warmup,
+                    scaling="strong" if strong else "weak",
+                    workload=f"{name} x{world if not strong else 1}: dp={prm.dp}, DL={prm.DL}, DH={prm.DH}, "
+                             f"n_fluid={parts['n_fluid']}, n_wall={parts['n_wall']}, n_total={nt}; start={start}",
+                    parallelism=f"{world} x-slabs (one rank per GPU), {HALO_COLS}-column halo, {loop}", slab0=lay,
+                    roofline={"bound": "hbm", "achieved": alg, "peak": 8000.0 * world, "unit": "GB/s",
+                              "frac": alg / (8000.0 * world), "traffic": None, "kernel": "whole step, all ranks"},
+                    sim={"t": st["t"], "dt": st["dt_last"], "vmax": st["vmax"]})
+
+    head = run_case(args.workload or "C2", args.steps, args.warmup)
+    aux = {}
+    if args.workload is None and not args.no_aux:
+        try:  # every rank takes the same path: partition() raises on all ranks or on none
+            partition(n_cell_columns(cfg.params_from_values(end_time=1e9, **workloads["C5"])), world)
+            aux["C5:strong"] = run_case("C5:strong", 40, 8)
+        except ValueError as e:
+            aux["C5:strong"] = {"error": repr(e)}
     if rank == 0:
         out = {
-            "metric": "particle-steps/s", "value": nt * args.steps / seconds, "unit": "particle-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * seconds / args.steps,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+            "metric": "particle-steps/s", "value": head["value"], "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{name} x{world if not strong else 1}: dp={prm.dp}, DL={prm.DL}, DH={prm.DH}, "
-                                   f"n_fluid={parts['n_fluid']}, n_wall={parts['n_wall']}, n_total={nt}; start={start}",
-                       "parallelism": f"{world} x-slabs (one rank per GPU), {HALO_COLS}-column halo, ring p2p + "
-                                      f"1-double max all-reduce per step over RCCL",
-                       "slab0": lay},
-            "roofline": {"bound": "hbm", "achieved": (528 * parts["n_fluid"] + 120 * parts["n_wall"]) * args.steps / seconds / 1e9,
-                         "peak": 8000.0 * world, "unit": "GB/s",
-                         "frac": (528 * parts["n_fluid"] + 120 * parts["n_wall"]) * args.steps / seconds / 1e9 / (8000.0 * world),
-                         "traffic": None, "kernel": "whole step, all ranks"},
-            "sim": {"t": st["t"], "dt": st["dt_last"], "vmax": st["vmax"]},
+            "config": {"workload": head["workload"], "parallelism": head["parallelism"], "slab0": head["slab0"]},
+            "roofline": head["roofline"], "sim": head["sim"],
         }
+        if aux:
+            out["aux"] = aux
         print(json.dumps(out))
-    eng.close()
     dist.destroy_process_group()

@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--dp", type=float, default=0.05)
     ap.add_argument("--DL", type=float, default=3.0)
     ap.add_argument("--lpp", type=int, default=0)
+    ap.add_argument("--native", action="store_true", help="hip engine: the library's own loop over RCCL (one GPU per rank)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -160,11 +161,21 @@ def main():
     prm, parts = make_case(pkg.config, pkg.geometry, dp=args.dp, DL=args.DL, jitter=0.2, seed=11, developed=True, end_time=1e9)
     nf = parts["n_fluid"]
     if args.engine == "hip":
-        eng = slab.HipSlabEngine(prm, parts, rank, world, 0, lanes_per_particle=args.lpp, t_end=1e9)
+        ndev = max(pkg.capi.device_count(), 1)
+        eng = slab.HipSlabEngine(prm, parts, rank, world, rank % ndev, lanes_per_particle=args.lpp, t_end=1e9, native=args.native)
     else:
         eng = OracleSlabEngine(prm, parts, rank, world, slab.HALO_COLS)
-    drv = slab.SlabDriver(eng, slab.RingExchange(rank, world))
-    st = drv.run_steps(args.steps)
+    if args.native:
+        ident = [slab.HipSlabEngine.unique_id(pkg.capi) if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        eng.comm_init(ident[0])
+        eng.run(args.steps)
+        st = eng.sync()
+        drv = slab.SlabDriver.__new__(slab.SlabDriver)
+        drv.e, drv.x, drv.steps_done = eng, slab.RingExchange(rank, world), args.steps
+    else:
+        drv = slab.SlabDriver(eng, slab.RingExchange(rank, world))
+        st = drv.run_steps(args.steps)
     got = drv.gather_owned(nf)
     ok = True
     if rank == 0:

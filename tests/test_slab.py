@@ -52,3 +52,46 @@ def test_slab_hip_two_ranks_half_million_particles():
     r = _launch(2, "--engine", "hip", "--steps", "4", "--dp", "0.005", "--DL", "12.0", port=29541)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "OK" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dp,DL,steps", [(2, 0.05, 3.0, 7), (3, 0.05, 3.0, 7), (4, 0.01, 6.0, 5)])
+def test_slab_native_ring_in_one_process(world, dp, DL, steps):
+    """The library's own step loop (sphx_slab_group_run: every slab of the ring in this process, device-to-device
+    copies as the transport, events for the ordering -- the loop sphx_slab_run runs over RCCL) against the single-GPU
+    context."""
+    import importlib
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import assert_close, make_case
+    pkg = importlib.import_module("sph-poiseuille-flow_amd")
+    slab = importlib.import_module("sph-poiseuille-flow_amd.slab")
+    prm, parts = make_case(pkg.config, pkg.geometry, dp=dp, DL=DL, jitter=0.2, seed=11, developed=True, end_time=1e9)
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    engines = [slab.HipSlabEngine(prm, parts, r, world, 0, t_end=1e9, native=True) for r in range(world)]
+    try:
+        slab.HipSlabEngine.group_run(engines, steps)
+        sts = [e.sync() for e in engines]
+        snaps = [e.snapshot() for e in engines]
+    finally:
+        for e in engines:
+            e.close()
+    pos, vel, drho = np.full((nf, 2), np.nan), np.full((nf, 2), np.nan), np.full(nf, np.nan)
+    seen = np.zeros(nf, dtype=int)
+    for sn in snaps:
+        o = sn["owned"]
+        i = sn["id"][o]
+        pos[i, 0], pos[i, 1], vel[i, 0], vel[i, 1], drho[i] = sn["x"][o], sn["y"][o], sn["vx"][o], sn["vy"][o], sn["drho"][o]
+        np.add.at(seen, i, 1)
+    assert np.all(seen == 1), (int((seen == 0).sum()), int((seen > 1).sum()))
+    with pkg.capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
+                          t_end=1e9) as ctx:
+        rs = ctx.advance(1e9, max_steps=steps)
+        ref = ctx.download(fields=("pos", "vel", "drho_dt"))
+    for st in sts:
+        assert st["step"] == steps and abs(st["t"] - rs["t"]) <= 1e-12 * rs["t"]
+    tol = dict(rtol=1e-9, atol_scale=1e-10)
+    assert_close(pos, ref["pos"][:nf], name="pos", **tol)
+    assert_close(vel, ref["vel"][:nf], name="vel", **tol)
+    assert_close(drho, ref["drho_dt"][:nf], name="drho_dt", **tol)
