@@ -54,7 +54,17 @@ struct Grid {
     double DL, half_DL;   // min-image: |dx| > half_DL -> dx -+ DL ; half_DL = +inf in an open window
     double x0, y0, inv_csx, inv_csy;
     double own_lo, own_hi;  // particles with own_lo <= x < own_hi are owned by this context
+    // Slabs that re-bin every K-th step: between two re-binnings ownership is frozen, it goes by the column a particle
+    // was BINNED into (own_c0 <= column < own_c1), not by where it has drifted since
+    int own_by_cell, own_c0, own_c1;
 };
+
+__device__ __forceinline__ bool owns(const Grid &g, double x, int cell)
+{
+    if (!g.own_by_cell) return x >= g.own_lo && x < g.own_hi;
+    const int cx = cell / g.ncy;
+    return cx >= g.own_c0 && cx < g.own_c1;
+}
 
 struct Phys {
     KernelConst kc;
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         yo += 0.5 * dt * vyi;
         xo += 0.5 * dt * vxn;
         yo += 0.5 * dt * vyn;
-        if (tracked) {
+        if (tracked && (!g.own_by_cell || owns(g, 0.0, s.cell[i]))) {  // (a slab bounds the drift of what it owns)
             const double ddx = min_image(g, xo - pb.x), ddy = yo - pb.y;
             d2 = ddx * ddx + ddy * ddy;
             if (d2 != d2) d2 = INFINITY;
@@ -1133,7 +1143,7 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
         yo += 0.5 * dt * vyi;
         xo += 0.5 * dt * vxn;
         yo += 0.5 * dt * vyn;
-        if (tracked) {
+        if (tracked && (!g.own_by_cell || owns(g, 0.0, s.cell[i]))) {  // (a slab bounds the drift of what it owns)
             const double ddx = min_image(g, xo - pb.x), ddy = yo - pb.y;
             d2 = ddx * ddx + ddy * ddy;
             if (d2 != d2) d2 = INFINITY;
@@ -1390,7 +1400,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
         t.drhon[i] = drho_new;
         t.rho_out[i] = rho;
         t.p_out[i] = eos_pressure(rho, ph.rho0, ph.p0);
-        if (xi >= g.own_lo && xi < g.own_hi) {
+        if (owns(g, xi, g.own_by_cell ? s.cell[i] : 0)) {
             v2 = vxi * vxi + vyi * vyi;
             if (v2 != v2) v2 = INFINITY;  // NaN poisons the max on purpose
         }
@@ -1614,6 +1624,7 @@ struct ReorderArgs {
     int *id_dst;
     int *src_of;
     int *cell_dst;  // binned cell of every destination slot (nullptr: not needed, walls)
+    int *slot_of_id;  // skinned slabs: particle id -> its slot in the new ordering (nullptr: not needed)
 };
 
 // Step kernel 7: canonical rank inside the cell (ascending particle id -> an order that does not
@@ -1645,6 +1656,7 @@ __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int
         a.id_dst[dst] = my_id;
         if (a.src_of) a.src_of[dst] = i;
         if (a.cell_dst) a.cell_dst[dst] = c;
+        if (a.slot_of_id) a.slot_of_id[my_id] = dst;
     }
 }
 
@@ -1688,13 +1700,13 @@ __global__ void k_row_any(Grid g, const int *wstart, int *row_any)
 
 // initial max |v| over owned particles (vecnorm over the fluid, SPH_Poiseuille.m:521); single block
 __global__ __launch_bounds__(kScanBlock) void k_vmax_init(Clock *clk, Grid g, const double2 *pos, const double2 *vel,
-                                                          double *vmax_out)
+                                                          double *vmax_out, const int *cell = nullptr)
 {
     const int n = clk->n;
     double m = 0.0;
     for (int k = threadIdx.x; k < n; k += kScanBlock) {
         const double x = pos[k].x;
-        if (!(x >= g.own_lo && x < g.own_hi)) continue;
+        if (!owns(g, x, (g.own_by_cell && cell) ? cell[k] : 0)) continue;
         const double2 v = vel[k];
         double v2 = v.x * v.x + v.y * v.y;
         if (v2 != v2) v2 = INFINITY;
@@ -2001,6 +2013,225 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const Clock *clk, int q,
         p.kmass[d] = b[5 * (size_t)cap + sl];
         p.kid[d] = (int)b[6 * (size_t)cap + sl];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Skinned slabs: a slab re-bins (and re-negotiates its halo) only on the K-th step or when the drift bound is hit -- the
+// device decides, from ALL-REDUCED max |v| and max drift, so every rank takes the same decision without the host.  In
+// between the layout is frozen: each rank sends the new state of a fixed list of boundary particles (send_idx) and the
+// receiver writes it into fixed slots (recv_slot); the lists are rebuilt with the layout.  Per step:
+//   passes A..E -> k_slab_seal2 -> [max all-reduce of {max|v|, max drift}] -> k_slab_decide -> k_slab_pack2
+//   -> [message A to both ring neighbours] -> k_slab_unpack2 -> {re-binning chain, k_slab_sendlist: only when the clock
+//   says so} -> [message B: the ids of my send lists] -> k_slab_recvslots
+// Ownership goes by the binned column (Grid::own_by_cell).  A particle that crosses a slab boundary changes owner at
+// the next re-binning: both ranks hold it (the old owner keeps everything in its window), the new owner names it in
+// its id list and the old owner finds its copy through slot_of_id.
+// ---------------------------------------------------------------------------------------------
+struct SlabLists {
+    int *send_idx[2];   // [msg_cap] slots whose state goes to the left / right neighbour every step
+    int *send_cnt;      // [2]
+    int *recv_slot[2];  // [msg_cap] slots the entries of the left / right neighbour's messages are written to
+    int *recv_cnt;      // [2]
+    int *slot_of_id;    // [global fluid count] particle id -> slot in the current layout (stale once a particle has left)
+    int *ids_send[2];   // message B, outgoing: [1 + msg_cap] count, ids (device buffers owned by the context)
+};
+
+// local max |v| and max drift of the owned particles -> out[0..1] (input of the all-reduce); single workgroup
+__global__ __launch_bounds__(kScanBlock) void k_slab_seal2(const Clock *clk, int q, int n_vpart, const double *vpart,
+                                                           const double *dpart, double *out)
+{
+    if (!clk->run[q]) { if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; } return; }
+    double m = 0.0, d = 0.0;
+    for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) { m = fmax(m, vpart[k]); d = fmax(d, dpart[k]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); d = fmax(d, __shfl_xor(d, off)); }
+    __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
+        out[0] = sqrt(m);
+        out[1] = sqrt(d);
+    }
+}
+
+// one thread: advance the clock with the global maxima and decide whether this step ends with a re-binning
+__global__ void k_slab_decide(Clock *clk, int q, Phys ph, const double *vd_global, const int *flags, double half_skin, int K)
+{
+    if (!clk->run[q]) { clk->run[1 - q] = 0; return; }
+    const Clock c0 = *clk;
+    clock_step(clk, c0, q, ph, vd_global[0], *flags, -1, vd_global[1], 0, half_skin, K);
+    if (clk->rebuild_now) clk->rebuild_now = 1;  // (no histogram is taken ahead of time in a slab)
+}
+
+// message A.  Frozen step: the new state of the send-list particles, in list order.  Re-binning step: every owned
+// particle's new state goes to `keep` (it stays in this window) and, near a boundary, to the neighbour -- as in
+// k_slab_pack.  sn = the NEW state (S[1-q]); layout arrays (mass, id, cell) are those of the step.
+__global__ __launch_bounds__(kBlock) void k_slab_pack2(const Clock *clk, int q, Grid g, FluidSet sn, SlabPack p, SlabLists L,
+                                                       int *flags)
+{
+    if (!clk->run[q]) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (!clk->rebuild_now) {
+        if (i >= 2 * p.msg_cap) return;
+        const int side = i < p.msg_cap ? 0 : 1, sl = i - side * p.msg_cap;
+        if (sl >= L.send_cnt[side]) return;
+        const int k = L.send_idx[side][sl];
+        const double2 pn = sn.pos[k], vn = sn.vel[k];
+        msg_put(side ? p.send_r : p.send_l, p.msg_cap, sl, pn.x + (side ? p.shift_r : p.shift_l), pn.y, vn.x, vn.y, sn.drho[k],
+                0.0, 0);
+        return;
+    }
+    if (i >= clk->n) return;
+    if (!owns(g, 0.0, sn.cell[i])) return;  // halo copy: its owner sends a fresh one
+    const double2 pn = sn.pos[i], vn = sn.vel[i];
+    const double xn = pn.x, yn = pn.y, dr = sn.drho[i], m = sn.mass[i];
+    const int id = sn.id[i];
+    if (xn >= p.win_lo && xn < p.win_hi) {
+        const int k = atomicAdd(&p.counters[0], 1);
+        if (k < p.keep_cap) {
+            p.kpos[k] = pn; p.kvel[k] = vn; p.kdrho[k] = dr; p.kmass[k] = m; p.kid[k] = id;
+            int cx, cy;
+            cell_of(g, xn, yn, cx, cy);
+            const int c = cx * g.ncy + cy;
+            p.cellid[k] = c;
+            atomicAdd(&p.count[c], 1);
+        } else atomicOr(flags, 2);
+    }
+    if (xn < g.own_lo + p.halo_w) {
+        const int k = atomicAdd(&p.counters[1], 1);
+        if (k < p.msg_cap) msg_put(p.send_l, p.msg_cap, k, xn + p.shift_l, yn, vn.x, vn.y, dr, m, id);
+        else atomicOr(flags, 2);
+    }
+    if (xn >= g.own_hi - p.halo_w) {
+        const int k = atomicAdd(&p.counters[2], 1);
+        if (k < p.msg_cap) msg_put(p.send_r, p.msg_cap, k, xn + p.shift_r, yn, vn.x, vn.y, dr, m, id);
+        else atomicOr(flags, 2);
+    }
+}
+
+// one thread: the message counts (a stopped loop sends -1)
+__global__ void k_slab_seal_msg(const Clock *clk, int q, SlabPack p, SlabLists L)
+{
+    const bool run = clk->run[q] != 0;
+    const bool rb = clk->rebuild_now != 0;
+    p.send_l[0] = !run ? -1.0 : (double)(rb ? min(p.counters[1], p.msg_cap) : L.send_cnt[0]);
+    p.send_r[0] = !run ? -1.0 : (double)(rb ? min(p.counters[2], p.msg_cap) : L.send_cnt[1]);
+}
+
+// message A, receiving side.  Frozen step: scatter the entries into their slots of the new state.  Re-binning step:
+// append them behind the kept particles and bin them (k_slab_unpack).
+__global__ __launch_bounds__(kBlock) void k_slab_unpack2(const Clock *clk, int q, Grid g, FluidSet sn, SlabPack p, SlabLists L,
+                                                         const double *recv_l, const double *recv_r, int *n_new, int *flags)
+{
+    if (!clk->run[q]) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int nl = (int)recv_l[0], nr = (int)recv_r[0];
+    const int cap = p.msg_cap;
+    if (!clk->rebuild_now) {
+        if (i == 0 && (nl != L.recv_cnt[0] || nr != L.recv_cnt[1])) atomicOr(flags, 2);  // the neighbours disagree with my lists
+        if (i >= 2 * cap) return;
+        const int side = i < cap ? 0 : 1, sl = i - side * cap;
+        if (sl >= L.recv_cnt[side]) return;
+        const double *b = (side ? recv_r : recv_l) + 1;
+        const int k = L.recv_slot[side][sl];
+        sn.pos[k] = make_double2(b[sl], b[(size_t)cap + sl]);
+        sn.vel[k] = make_double2(b[2 * (size_t)cap + sl], b[3 * (size_t)cap + sl]);
+        sn.drho[k] = b[4 * (size_t)cap + sl];
+        return;
+    }
+    const int nk = min(p.counters[0], p.keep_cap);
+    if (nl < 0 || nr < 0 || nk + nl + nr > p.keep_cap) {
+        if (i == 0) { atomicOr(flags, 2); *n_new = min(nk, p.keep_cap); }
+        return;
+    }
+    if (i == 0) *n_new = nk + nl + nr;
+    if (i < nl + nr) {
+        const double *b = (i < nl ? recv_l : recv_r) + 1;
+        const int sl = i < nl ? i : i - nl;
+        const int d = nk + i;
+        const double x = b[sl], y = b[(size_t)cap + sl];
+        p.kpos[d] = make_double2(x, y);
+        int cx, cy;
+        cell_of(g, x, y, cx, cy);
+        const int c = cx * g.ncy + cy;
+        p.cellid[d] = c;
+        atomicAdd(&p.count[c], 1);
+        p.kvel[d] = make_double2(b[2 * (size_t)cap + sl], b[3 * (size_t)cap + sl]);
+        p.kdrho[d] = b[4 * (size_t)cap + sl];
+        p.kmass[d] = b[5 * (size_t)cap + sl];
+        p.kid[d] = (int)b[6 * (size_t)cap + sl];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_slot_of_id(int n, const int *id, int *slot_of_id)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) slot_of_id[id[i]] = i;
+}
+
+// one thread, re-binning steps: the particle count of the new layout, counters back to zero
+__global__ void k_slab_begin_rebin(Clock *clk, int q, const int *n_new, int *pack_counters, int *send_cnt)
+{
+    if (!clk->run[q] || !clk->rebuild_now) return;
+    clk->n = *n_new;
+    pack_counters[0] = 0; pack_counters[1] = 0; pack_counters[2] = 0;
+    send_cnt[0] = 0; send_cnt[1] = 0;
+}
+
+// re-binning steps, on the NEW layout: owned particles within halo_w of a boundary form the send lists of the cycle;
+// their ids are message B
+__global__ __launch_bounds__(kBlock) void k_slab_sendlist(const Clock *clk, int q, Grid g, FluidSet sn, SlabPack p, SlabLists L,
+                                                          int *flags, int force)
+{
+    if (!force && (!clk->run[q] || !clk->rebuild_now)) return;  // force: the lists of the first cycle
+    const int n = clk->n;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (!owns(g, 0.0, sn.cell[i])) continue;
+        const double x = sn.pos[i].x;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const bool near = side ? x >= g.own_hi - p.halo_w : x < g.own_lo + p.halo_w;
+            if (!near) continue;
+            const int k = atomicAdd(&L.send_cnt[side], 1);
+            if (k < p.msg_cap) {
+                L.send_idx[side][k] = i;
+                L.ids_send[side][1 + k] = sn.id[i];
+            } else atomicOr(flags, 2);
+        }
+    }
+}
+
+// one thread: header of message B (-1: the lists of the cycle stay)
+__global__ void k_slab_seal_ids(const Clock *clk, int q, SlabPack p, SlabLists L, int force)
+{
+    const bool rb = force || (clk->run[q] && clk->rebuild_now);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        if (rb) L.send_cnt[side] = min(L.send_cnt[side], p.msg_cap);
+        L.ids_send[side][0] = rb ? L.send_cnt[side] : -1;
+    }
+}
+
+// message B, receiving side: where do the particles the neighbours will keep sending live here?
+__global__ __launch_bounds__(kBlock) void k_slab_recvslots(const Clock *clk, int q, SlabPack p, SlabLists L, const int *ids_l,
+                                                           const int *ids_r, const int *id_of_slot, int *flags, int force)
+{
+    if (!force && (!clk->run[q] || !clk->rebuild_now)) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= 2 * p.msg_cap) return;
+    const int side = i < p.msg_cap ? 0 : 1, sl = i - side * p.msg_cap;
+    const int *ids = side ? ids_r : ids_l;
+    const int cnt = ids[0];
+    if (sl == 0) {
+        if (cnt < 0 || cnt > p.msg_cap) atomicOr(flags, 2);
+        L.recv_cnt[side] = max(0, min(cnt, p.msg_cap));
+    }
+    if (sl >= cnt || sl >= p.msg_cap) return;
+    const int id = ids[1 + sl];
+    const int k = L.slot_of_id[id];
+    if (k < 0 || k >= clk->n || id_of_slot[k] != id) { atomicOr(flags, 2); return; }  // I do not hold that particle
+    L.recv_slot[side][sl] = k;
 }
 
 }  // namespace sphx

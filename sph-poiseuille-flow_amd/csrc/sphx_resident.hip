@@ -142,7 +142,11 @@ struct sphx_ctx {
     // optional (SPHX_SLAB_GRAPH=1): each half-step captured once per parity (and per buffer set) and replayed;
     // slower than plain launches for graphs this small, see slab_half
     // native step loop (sphx_slab_run / sphx_slab_group_run): library-owned message buffers, RCCL communicator
-    DevBuf<double> msg_sl, msg_sr, msg_rl, msg_rr, vmax_l, vmax_g;
+    DevBuf<double> msg_sl, msg_sr, msg_rl, msg_rr, vmax_l, vmax_g;  // (vmax_*: {max |v|, max drift})
+    // skinned slabs (re-binning every K-th step): the exchange lists of the cycle, see SlabLists
+    DevBuf<int> send_idx_[2], recv_slot_[2], send_cnt, recv_cnt, slot_of_id, ids_s_[2], ids_r_[2];
+    SlabLists lists{};
+    bool lists_ready = false;
     ncclComm_t comm = nullptr;
     hipEvent_t ev_computed = nullptr, ev_received = nullptr;  // single-process ring: cross-stream ordering
     hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
@@ -218,7 +222,7 @@ void launch(sphx_ctx *c, const char *name, K kernel, dim3 grid, dim3 block, Args
 
 // gather of the persistent fields (pos, vel, drho, mass) into destination view d
 ReorderArgs reorder_args(const double2 *pos, const double2 *vel, const double *drho, const double *mass, const int *id_src,
-                         const FluidSet &d, int *src_of)
+                         const FluidSet &d, int *src_of, int *slot_of_id = nullptr)
 {
     ReorderArgs ra{};
     ra.n2 = 2;
@@ -235,6 +239,7 @@ ReorderArgs reorder_args(const double2 *pos, const double2 *vel, const double *d
     ra.id_dst = d.id;
     ra.src_of = src_of;
     ra.cell_dst = d.cell;
+    ra.slot_of_id = slot_of_id;
     return ra;
 }
 
@@ -1396,8 +1401,18 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     const double *px = pos, *py = pos + ntz;
     double y_min, y_max;
     y_extent(py, n_total, y_min, y_max);
-    const double cs = 2.0 * prm->h, DL = prm->DL;
+    // Re-binning interval of the slab: 1 = every step (the protocol of sphx_slab_compute / _finish, a caller-driven
+    // transport); K > 1 (0 = auto: 5) = every K-th step with a cell skin, frozen layouts and fixed exchange lists in between
+    // (the native loops sphx_slab_run / sphx_slab_group_run only).
+    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : 5;
+    const double d_step = 0.035 * prm->h;
+    double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
+    c->rebuild_every = K;
+    c->skin = skin;
+    c->dyn = K > 1;  // the device decides when to re-bin (from all-reduced maxima), the layout is rebuilt in place
+    const double cs = 2.0 * prm->h + skin, DL = prm->DL;
     const int ncx_g = (int)std::floor(DL / cs);
+    require(ncx_g >= 3, "SPH:Neighbor:param", "channel too short for three cell columns.");
     const double csx = DL / ncx_g;
     const int H = halo_cols;
     auto col_lo = [&](int r) { return (int)(((long long)r * ncx_g) / n_ranks); };
@@ -1421,6 +1436,9 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     g.inv_csy = 1.0 / cs;
     g.own_lo = (double)c->col0 * csx;
     g.own_hi = (rank == n_ranks - 1) ? DL : (double)c->col1 * csx;
+    g.own_by_cell = K > 1 ? 1 : 0;
+    g.own_c0 = H;
+    g.own_c1 = H + (c->col1 - c->col0);
     c->grid = g;
     c->phys = make_phys(prm);
     const double win_lo = g.x0, win_hi = g.x0 + (double)g.ncx * csx;
@@ -1441,7 +1459,9 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     // capacities: message = (H+2) columns at twice the mean column load; arrays = window at 1.5x + messages
     const double per_col = (double)n_fluid / ncx_g;
     c->msg_cap = (int)(2.0 * (H + 2) * per_col) + 1024;
-    const int cap = (int)(1.5 * per_col * g.ncx) + 2 * c->msg_cap + 1024;
+    // (every kernel is launched for `cap` particles: slack costs time -- 15 % headroom over the initial population of this
+    // weakly compressible flow; an overflow raises SPHX_ERR_GRID on the device, never a silent loss)
+    const int cap = (int)(1.15 * std::max<double>(n_local, per_col * g.ncx)) + 2 * c->msg_cap + 1024;
     require(n_local <= cap, "SPHX:Slab:capacity", "initial slab population exceeds capacity");
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(n_local);
@@ -1474,6 +1494,23 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     p.msg_cap = c->msg_cap;
     p.keep_cap = cap;
     c->pack = p;
+    if (K > 1) {
+        for (int k = 0; k < 2; ++k) {
+            c->send_idx_[k].alloc(c->msg_cap); c->recv_slot_[k].alloc(c->msg_cap);
+            c->ids_s_[k].alloc((size_t)c->msg_cap + 1); c->ids_r_[k].alloc((size_t)c->msg_cap + 1);
+            c->ids_s_[k].zero(c->stream); c->ids_r_[k].zero(c->stream);
+        }
+        c->send_cnt.alloc(2); c->recv_cnt.alloc(2); c->slot_of_id.alloc((size_t)n_fluid);
+        c->send_cnt.zero(c->stream); c->recv_cnt.zero(c->stream);
+        SPHX_HIP(hipMemsetAsync(c->slot_of_id.get(), 0xFF, (size_t)n_fluid * sizeof(int), c->stream));
+        c->lists = SlabLists{{c->send_idx_[0].get(), c->send_idx_[1].get()}, c->send_cnt.get(),
+                             {c->recv_slot_[0].get(), c->recv_slot_[1].get()}, c->recv_cnt.get(), c->slot_of_id.get(),
+                             {c->ids_s_[0].get(), c->ids_s_[1].get()}};
+        if (n_local > 0)
+            hipLaunchKernelGGL(k_slot_of_id, dim3(div_up(n_local, kBlock)), dim3(kBlock), 0, c->stream, n_local,
+                               (const int *)c->fid_[0].get(), c->slot_of_id.get());
+        SPHX_HIP(hipGetLastError());
+    }
     init_clock(c, n_local, t0, step0);
     c->slab_step0 = step0;
     read_clock(c);
@@ -1638,6 +1675,7 @@ SPHX_EXPORT int sphx_slab_compute(sphx_ctx *c, double *send_left_dev, double *se
     SPHX_TRY
     require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
     require(send_left_dev && send_right_dev && vmax_local_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
+    require(c->rebuild_every == 1, "SPHX:Slab:protocol", "compute/finish drive a slab created with rebuild_every = 1");
     slab_compute_impl(c, send_left_dev, send_right_dev, vmax_local_dev);
     return SPHX_OK;
     SPHX_CATCH
@@ -1714,7 +1752,7 @@ void slab_native_buffers(sphx_ctx *c)
     if (c->msg_sl.get()) return;
     const size_t n = 1 + 7 * (size_t)c->msg_cap;
     c->msg_sl.alloc(n); c->msg_sr.alloc(n); c->msg_rl.alloc(n); c->msg_rr.alloc(n);
-    c->vmax_l.alloc(1); c->vmax_g.alloc(1);
+    c->vmax_l.alloc(2); c->vmax_g.alloc(2);
     for (DevBuf<double> *b : {&c->msg_sl, &c->msg_sr, &c->msg_rl, &c->msg_rr, &c->vmax_l, &c->vmax_g}) b->zero(c->stream);
 }
 
@@ -1722,11 +1760,12 @@ struct PtrList {
     const double *p[16];
 };
 // max of one double per rank (single-process ring: stands in for the all-reduce)
-__global__ void k_max_of(int n, PtrList src, double *out)
+__global__ void k_max_of(int n, PtrList src, double *out)  // thread j: component j of {max |v|, max drift}
 {
-    double m = src.p[0][0];
-    for (int k = 1; k < n; ++k) m = fmax(m, src.p[k][0]);
-    *out = m;
+    const int j = threadIdx.x;
+    double m = src.p[0][j];
+    for (int k = 1; k < n; ++k) m = fmax(m, src.p[k][j]);
+    out[j] = m;
 }
 
 }  // namespace
@@ -1772,6 +1811,97 @@ SPHX_EXPORT int sphx_slab_comm_destroy(sphx_ctx *c)
     SPHX_CATCH
 }
 
+namespace {
+
+// ---- one step of a skinned slab, in four phases separated by the three exchanges (see SlabLists) ----
+FluidSet slab_new_state(sphx_ctx *c) { return c->view(1 - c->cur, 0); }  // S[1-q] with the (in-place) layout arrays
+
+void slab_phase1(sphx_ctx *c)  // passes A..E into S[1-q], local maxima -> vmax_l[0..1]
+{
+    const int q = c->cur;
+    const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
+    FluidTmp t = c->tmp;
+    t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+    launch_physics_any(c, q, s, t, 0, 0, 3);
+    launch(c, "k_slab_seal2", k_slab_seal2, dim3(1), dim3(kScanBlock), (const Clock *)c->clock.get(), q, c->n_vpart,
+           (const double *)c->vpart.get(), (const double *)c->dpart.get(), c->vmax_l.get());
+}
+
+void slab_phase2(sphx_ctx *c)  // global maxima known: clock + re-binning decision, message A
+{
+    const int q = c->cur;
+    Clock *clk = c->clock.get();
+    launch(c, "k_slab_decide", k_slab_decide, dim3(1), dim3(1), clk, q, c->phys, (const double *)c->vmax_g.get(),
+           (const int *)c->flags.get(), c->half_skin(), c->rebuild_every);
+    SlabPack p = c->pack;
+    p.send_l = c->msg_sl.get();
+    p.send_r = c->msg_sr.get();
+    const unsigned nb = std::max<unsigned>(c->n_blocks_flat, div_up((size_t)2 * c->msg_cap, kBlock));
+    launch(c, "k_slab_pack2", k_slab_pack2, dim3(nb), dim3(kBlock), (const Clock *)clk, q, c->grid, slab_new_state(c), p, c->lists,
+           c->flags.get());
+    launch(c, "k_slab_seal_msg", k_slab_seal_msg, dim3(1), dim3(1), (const Clock *)clk, q, p, c->lists);
+}
+
+void slab_phase3(sphx_ctx *c)  // message A arrived: refresh the halo copies, or re-bin and make the lists of the next cycle
+{
+    const int q = c->cur, qf = q | kOnlyIfRebuild;
+    Clock *clk = c->clock.get();
+    const FluidSet d = slab_new_state(c);
+    launch(c, "k_slab_unpack2", k_slab_unpack2, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock), (const Clock *)clk, q,
+           c->grid, d, c->pack, c->lists, (const double *)c->msg_rl.get(), (const double *)c->msg_rr.get(), c->n_new.get(),
+           c->flags.get());
+    launch(c, "k_slab_begin_rebin", k_slab_begin_rebin, dim3(1), dim3(1), clk, q, (const int *)c->n_new.get(), c->counters.get(),
+           c->send_cnt.get());
+    const int kRebinBlocks = 4096;  // grid-stride: on the steps that do not re-bin these launches return at once
+    launch_cell_scan(c, clk, qf, d.start);
+    launch_scatter_reorder(c, clk, qf,
+                           reorder_args(c->kpos.get(), c->kvel.get(), c->kdrho.get(), c->kmass.get(), c->kid.get(), d, nullptr,
+                                        c->slot_of_id.get()),
+                           d, kRebinBlocks);
+    launch(c, "k_slab_sendlist", k_slab_sendlist, dim3(std::min(c->n_blocks_flat, kRebinBlocks)), dim3(kBlock), (const Clock *)clk,
+           q, c->grid, d, c->pack, c->lists, c->flags.get(), 0);
+    launch(c, "k_slab_seal_ids", k_slab_seal_ids, dim3(1), dim3(1), (const Clock *)clk, q, c->pack, c->lists, 0);
+}
+
+void slab_phase4(sphx_ctx *c)  // message B arrived
+{
+    const int q = c->cur;
+    launch(c, "k_slab_recvslots", k_slab_recvslots, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock),
+           (const Clock *)c->clock.get(), q, c->pack, c->lists, (const int *)c->ids_r_[0].get(), (const int *)c->ids_r_[1].get(),
+           (const int *)slab_new_state(c).id, c->flags.get(), 0);
+    SPHX_HIP(hipGetLastError());
+    c->cur ^= 1;
+    c->slab_steps_enqueued += 1;
+}
+
+// the exchange lists of the first cycle (the layout of slab_setup): send lists + ids out, then (ids in) receive slots
+void slab_lists_out(sphx_ctx *c)
+{
+    const FluidSet d = c->view(c->cur, 0);
+    SPHX_HIP(hipMemsetAsync(c->send_cnt.get(), 0, 2 * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_slab_sendlist, dim3(std::min(c->n_blocks_flat, 4096)), dim3(kBlock), 0, c->stream,
+                       (const Clock *)c->clock.get(), 0, c->grid, d, c->pack, c->lists, c->flags.get(), 1);
+    hipLaunchKernelGGL(k_slab_seal_ids, dim3(1), dim3(1), 0, c->stream, (const Clock *)c->clock.get(), 0, c->pack, c->lists, 1);
+}
+void slab_lists_in(sphx_ctx *c)
+{
+    hipLaunchKernelGGL(k_slab_recvslots, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock), 0, c->stream,
+                       (const Clock *)c->clock.get(), 0, c->pack, c->lists, (const int *)c->ids_r_[0].get(),
+                       (const int *)c->ids_r_[1].get(), (const int *)c->view(c->cur, 0).id, c->flags.get(), 1);
+    SPHX_HIP(hipGetLastError());
+    c->lists_ready = true;
+}
+
+void slab_local_maxima(sphx_ctx *c)  // arming: max |v| of the owned particles of the current state, drift 0
+{
+    const FluidSet fs = c->view(c->cur, c->rebuild_every > 1 ? 0 : c->cur);
+    SPHX_HIP(hipMemsetAsync(c->vmax_l.get(), 0, 2 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, c->stream, c->clock.get(), c->grid, (const double2 *)fs.pos,
+                       (const double2 *)fs.vel, c->vmax_l.get(), (const int *)fs.cell);
+}
+
+}  // namespace
+
 SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
 {
     SPHX_TRY
@@ -1781,28 +1911,45 @@ SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
     Rccl &R = Rccl::get();
     hipStream_t st = c->stream;
     const int left = (c->rank + c->n_ranks - 1) % c->n_ranks, right = (c->rank + 1) % c->n_ranks;
-    const size_t n_msg = 1 + 7 * (size_t)c->msg_cap;
+    const size_t n_msg = 1 + 7 * (size_t)c->msg_cap, n_ids = 1 + (size_t)c->msg_cap;
     double *sl = c->msg_sl.get(), *sr = c->msg_sr.get(), *rl = c->msg_rl.get(), *rr = c->msg_rr.get();
     double *vl = c->vmax_l.get(), *vg = c->vmax_g.get();
+    const bool skinned = c->rebuild_every > 1;
+    // My left message is my left neighbour's "from the right" message and vice versa; with two ranks both go to the same
+    // peer, which posts its receives in the order the sends are posted here.
+    auto ring = [&](const void *to_l, const void *to_r, void *from_l, void *from_r, size_t count, ncclDataType_t ty) {
+        R.check(R.GroupStart(), "ncclGroupStart");
+        R.check(R.Send(to_l, count, ty, left, c->comm, st), "ncclSend");
+        R.check(R.Send(to_r, count, ty, right, c->comm, st), "ncclSend");
+        R.check(R.Recv(from_r, count, ty, right, c->comm, st), "ncclRecv");
+        R.check(R.Recv(from_l, count, ty, left, c->comm, st), "ncclRecv");
+        R.check(R.GroupEnd(), "ncclGroupEnd");
+    };
     // arm the clock with the global max |v| of the current state
-    const FluidSet fs = c->view(c->cur, c->cur);
-    hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, st, c->clock.get(), c->grid, (const double2 *)fs.pos,
-                       (const double2 *)fs.vel, vl);
-    R.check(R.AllReduce(vl, vg, 1, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
+    slab_local_maxima(c);
+    R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, st, c->clock.get(), c->phys, t_target, (long long)n_steps, c->cur,
                        (const double *)vg);
+    if (skinned && !c->lists_ready) {
+        slab_lists_out(c);
+        ring(c->ids_s_[0].get(), c->ids_s_[1].get(), c->ids_r_[0].get(), c->ids_r_[1].get(), n_ids, ncclInt32);
+        slab_lists_in(c);
+    }
     for (int64_t k = 0; k < n_steps; ++k) {
-        slab_compute_impl(c, sl, sr, vl);
-        R.check(R.AllReduce(vl, vg, 1, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
-        // my left message is my left neighbour's "from the right" message and vice versa; with two ranks both go to
-        // the same peer, which posts its receives in the order the sends are posted here
-        R.check(R.GroupStart(), "ncclGroupStart");
-        R.check(R.Send(sl, n_msg, ncclDouble, left, c->comm, st), "ncclSend");
-        R.check(R.Send(sr, n_msg, ncclDouble, right, c->comm, st), "ncclSend");
-        R.check(R.Recv(rr, n_msg, ncclDouble, right, c->comm, st), "ncclRecv");
-        R.check(R.Recv(rl, n_msg, ncclDouble, left, c->comm, st), "ncclRecv");
-        R.check(R.GroupEnd(), "ncclGroupEnd");
-        slab_finish_impl(c, rl, rr, vg);
+        if (!skinned) {
+            slab_compute_impl(c, sl, sr, vl);
+            R.check(R.AllReduce(vl, vg, 1, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
+            ring(sl, sr, rl, rr, n_msg, ncclDouble);
+            slab_finish_impl(c, rl, rr, vg);
+        } else {
+            slab_phase1(c);
+            R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
+            slab_phase2(c);
+            ring(sl, sr, rl, rr, n_msg, ncclDouble);
+            slab_phase3(c);
+            ring(c->ids_s_[0].get(), c->ids_s_[1].get(), c->ids_r_[0].get(), c->ids_r_[1].get(), n_ids, ncclInt32);
+            slab_phase4(c);
+        }
     }
     SPHX_HIP(hipGetLastError());
     return SPHX_OK;
@@ -1819,6 +1966,8 @@ SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int
         sphx_ctx *c = ctxs[r];
         require(c != nullptr && c->is_slab && c->rank == r && c->n_ranks == n, "SPHX:Slab:group",
                 "ctxs[r] must be slab r of an n-slab ring");
+        require(c->msg_cap == ctxs[0]->msg_cap && c->rebuild_every == ctxs[0]->rebuild_every, "SPHX:Slab:group",
+                "slabs of one ring share the message capacity and the re-binning interval");
         slab_native_buffers(c);
         if (!c->ev_computed) {
             SPHX_HIP(hipEventCreateWithFlags(&c->ev_computed, hipEventDisableTiming));
@@ -1826,43 +1975,88 @@ SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int
         }
         vls.p[r] = c->vmax_l.get();
     }
-    // every rank: local max |v| -> (all ranks ready) -> global max -> arm
+    const bool skinned = ctxs[0]->rebuild_every > 1;
+    const size_t msg_bytes = (1 + 7 * (size_t)ctxs[0]->msg_cap) * sizeof(double);
+    const size_t ids_bytes = (1 + (size_t)ctxs[0]->msg_cap) * sizeof(int);
+    // A phase boundary of the ring: every rank records "my outputs of this phase are complete" and, before it touches
+    // anything another rank produced (or overwrites what another rank may still be reading), waits for all the others.
+    auto done = [&](hipEvent_t sphx_ctx::*ev) {
+        for (int r = 0; r < n; ++r) SPHX_HIP(hipEventRecord(ctxs[r]->*ev, ctxs[r]->stream));
+    };
+    auto wait_others = [&](int r, hipEvent_t sphx_ctx::*ev) {
+        for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(ctxs[r]->stream, ctxs[o]->*ev, 0));
+    };
+    auto max_of_all = [&](sphx_ctx *c) {
+        hipLaunchKernelGGL(k_max_of, dim3(1), dim3(2), 0, c->stream, n, vls, c->vmax_g.get());
+    };
+    auto copy_msgs = [&](int r) {  // what my ring neighbours addressed to me
+        sphx_ctx *c = ctxs[r], *L = ctxs[(r + n - 1) % n], *Rr = ctxs[(r + 1) % n];
+        SPHX_HIP(hipMemcpyAsync(c->msg_rl.get(), L->msg_sr.get(), msg_bytes, hipMemcpyDeviceToDevice, c->stream));
+        SPHX_HIP(hipMemcpyAsync(c->msg_rr.get(), Rr->msg_sl.get(), msg_bytes, hipMemcpyDeviceToDevice, c->stream));
+    };
+    auto copy_ids = [&](int r) {
+        sphx_ctx *c = ctxs[r], *L = ctxs[(r + n - 1) % n], *Rr = ctxs[(r + 1) % n];
+        SPHX_HIP(hipMemcpyAsync(c->ids_r_[0].get(), L->ids_s_[1].get(), ids_bytes, hipMemcpyDeviceToDevice, c->stream));
+        SPHX_HIP(hipMemcpyAsync(c->ids_r_[1].get(), Rr->ids_s_[0].get(), ids_bytes, hipMemcpyDeviceToDevice, c->stream));
+    };
+    // arm: local maxima -> global -> clock; first exchange lists
+    for (int r = 0; r < n; ++r) slab_local_maxima(ctxs[r]);
+    done(&sphx_ctx::ev_computed);
     for (int r = 0; r < n; ++r) {
         sphx_ctx *c = ctxs[r];
-        const FluidSet fs = c->view(c->cur, c->cur);
-        hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, c->stream, c->clock.get(), c->grid, (const double2 *)fs.pos,
-                           (const double2 *)fs.vel, c->vmax_l.get());
-        SPHX_HIP(hipEventRecord(c->ev_computed, c->stream));
-    }
-    for (int r = 0; r < n; ++r) {
-        sphx_ctx *c = ctxs[r];
-        for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(c->stream, ctxs[o]->ev_computed, 0));
-        hipLaunchKernelGGL(k_max_of, dim3(1), dim3(1), 0, c->stream, n, vls, c->vmax_g.get());
+        wait_others(r, &sphx_ctx::ev_computed);
+        max_of_all(c);
         hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target, (long long)n_steps, c->cur,
                            (const double *)c->vmax_g.get());
-        SPHX_HIP(hipEventRecord(c->ev_received, c->stream));
+        if (skinned && !c->lists_ready) slab_lists_out(c);
     }
-    const size_t msg_bytes = (1 + 7 * (size_t)ctxs[0]->msg_cap) * sizeof(double);
-    for (int r = 1; r < n; ++r)
-        require(ctxs[r]->msg_cap == ctxs[0]->msg_cap, "SPHX:Slab:group", "slabs of one ring share the message capacity");
+    done(&sphx_ctx::ev_received);
+    if (skinned && !ctxs[0]->lists_ready) {
+        for (int r = 0; r < n; ++r) {
+            wait_others(r, &sphx_ctx::ev_received);
+            copy_ids(r);
+            slab_lists_in(ctxs[r]);
+        }
+        done(&sphx_ctx::ev_received);
+    }
     for (int64_t k = 0; k < n_steps; ++k) {
         for (int r = 0; r < n; ++r) {
             sphx_ctx *c = ctxs[r];
-            // the others must have consumed my previous messages and my previous local max before I overwrite them
-            for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(c->stream, ctxs[o]->ev_received, 0));
-            slab_compute_impl(c, c->msg_sl.get(), c->msg_sr.get(), c->vmax_l.get());
-            SPHX_HIP(hipEventRecord(c->ev_computed, c->stream));
+            wait_others(r, &sphx_ctx::ev_received);  // the others have consumed my previous messages and maxima
+            if (skinned) slab_phase1(c);
+            else slab_compute_impl(c, c->msg_sl.get(), c->msg_sr.get(), c->vmax_l.get());
         }
-        for (int r = 0; r < n; ++r) {
+        done(&sphx_ctx::ev_computed);
+        if (!skinned) {
+            for (int r = 0; r < n; ++r) {
+                sphx_ctx *c = ctxs[r];
+                wait_others(r, &sphx_ctx::ev_computed);
+                copy_msgs(r);
+                max_of_all(c);
+            }
+            done(&sphx_ctx::ev_received);
+            for (int r = 0; r < n; ++r) slab_finish_impl(ctxs[r], ctxs[r]->msg_rl.get(), ctxs[r]->msg_rr.get(), ctxs[r]->vmax_g.get());
+            continue;
+        }
+        for (int r = 0; r < n; ++r) {  // "all-reduce", decision, message A
             sphx_ctx *c = ctxs[r];
-            sphx_ctx *L = ctxs[(r + n - 1) % n], *Rr = ctxs[(r + 1) % n];
-            for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(c->stream, ctxs[o]->ev_computed, 0));
-            SPHX_HIP(hipMemcpyAsync(c->msg_rl.get(), L->msg_sr.get(), msg_bytes, hipMemcpyDeviceToDevice, c->stream));
-            SPHX_HIP(hipMemcpyAsync(c->msg_rr.get(), Rr->msg_sl.get(), msg_bytes, hipMemcpyDeviceToDevice, c->stream));
-            hipLaunchKernelGGL(k_max_of, dim3(1), dim3(1), 0, c->stream, n, vls, c->vmax_g.get());
-            SPHX_HIP(hipEventRecord(c->ev_received, c->stream));
-            slab_finish_impl(c, c->msg_rl.get(), c->msg_rr.get(), c->vmax_g.get());
+            wait_others(r, &sphx_ctx::ev_computed);
+            max_of_all(c);
+            slab_phase2(c);
         }
+        done(&sphx_ctx::ev_received);  // (reused: "my maxima have been read by me, my message A is complete")
+        for (int r = 0; r < n; ++r) {  // message A in, re-binning chain, message B out
+            wait_others(r, &sphx_ctx::ev_received);
+            copy_msgs(r);
+            slab_phase3(ctxs[r]);
+        }
+        done(&sphx_ctx::ev_computed);
+        for (int r = 0; r < n; ++r) {  // message B in
+            wait_others(r, &sphx_ctx::ev_computed);
+            copy_ids(r);
+            slab_phase4(ctxs[r]);
+        }
+        done(&sphx_ctx::ev_received);
     }
     SPHX_HIP(hipGetLastError());
     return SPHX_OK;
@@ -1898,21 +2092,27 @@ SPHX_EXPORT int sphx_slab_snapshot(sphx_ctx *c, int capacity, int *n, double *x,
     const int m = c->h_clock->n;
     *n = m;
     require(capacity >= m, "SPHX:Slab:capacity", "snapshot arrays are too short");
-    const FluidSet fs = c->view(c->cur, c->cur);
+    const bool skinned = c->rebuild_every > 1;
+    const FluidSet fs = c->view(c->cur, skinned ? 0 : c->cur);
     hipStream_t s = c->stream;
     auto dl = [&](const void *src, void *dst, size_t bytes) {
         if (dst && m) SPHX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
     };
     std::vector<double2> hp((size_t)std::max(m, 1)), hv((size_t)std::max(m, 1));
+    std::vector<int> hcell((size_t)std::max(m, 1), 0);
     dl(fs.pos, hp.data(), (size_t)m * 16); dl(fs.vel, hv.data(), (size_t)m * 16);
     dl(fs.drho, drho, (size_t)m * 8); dl(fs.id, id, (size_t)m * 4);
+    if (skinned) dl(fs.cell, hcell.data(), (size_t)m * 4);  // ownership goes by the binned column
     SPHX_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < m; ++i) {
         if (x) x[i] = hp[i].x;
         if (y) y[i] = hp[i].y;
         if (vx) vx[i] = hv[i].x;
         if (vy) vy[i] = hv[i].y;
-        if (owned) owned[i] = (hp[i].x >= c->grid.own_lo && hp[i].x < c->grid.own_hi) ? 1 : 0;
+        if (owned) {
+            const int cx = hcell[i] / c->grid.ncy;
+            owned[i] = skinned ? (cx >= c->grid.own_c0 && cx < c->grid.own_c1) : (hp[i].x >= c->grid.own_lo && hp[i].x < c->grid.own_hi);
+        }
     }
     return SPHX_OK;
     SPHX_CATCH

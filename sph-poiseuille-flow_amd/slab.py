@@ -111,7 +111,7 @@ class HipSlabEngine:
     """libsphx slab context of one rank; device buffers are torch tensors so RCCL can move them."""
 
     def __init__(self, prm, parts, rank, world, device, lanes_per_particle=0, halo_cols=HALO_COLS, t_end=None,
-                 pos=None, vel=None, drho_dt=None, native=False):
+                 pos=None, vel=None, drho_dt=None, native=False, rebuild_every=0, skin_h=0.0):
         """native=True: the context runs on a stream of its own and keeps its message buffers inside the library (the
         native loop: run() over RCCL, or group_run() for a ring living in one process); no torch tensors involved."""
         from . import capi
@@ -124,7 +124,9 @@ class HipSlabEngine:
             self.device = torch.device("cuda", device)
             torch.cuda.set_device(self.device)
             self.stream = torch.cuda.Stream(device=self.device)
-        self.params = capi.make_params(prm, t_end, None, lanes_per_particle, 0)
+        # the caller-driven protocol (compute / exchange / finish) re-bins every step; the native loops re-bin every
+        # rebuild_every-th step (0 = auto) with a cell skin and fixed exchange lists in between
+        self.params = capi.make_params(prm, t_end, None, lanes_per_particle, 0, rebuild_every if native else 1, skin_h)
         nf, nt = parts["n_fluid"], parts["n_total"]
         f = capi.f64
         pos = f(parts["pos"] if pos is None else pos)
