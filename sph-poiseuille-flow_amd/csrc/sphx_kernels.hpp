@@ -181,6 +181,15 @@ __device__ __forceinline__ int xcd_block(int b, int nb)
     return b < (per << 3) ? (b & 7) * per + (b >> 3) : b;
 }
 
+// A period of one or two cell columns (DL < 6h): the columns cx-1, cx, cx+1 are not distinct -- the reference meets the
+// same particle as a real and as a ghost entry there and de-duplicates with seen_neighbor
+// (mex/sph_neighbor_search_mex.c:282-295,342,383); here each distinct column is swept once and the minimum-image fold
+// picks the nearest image.
+__device__ __forceinline__ bool duplicate_column(const Grid &g, int ox)
+{
+    return (g.ncx == 1 && ox != 0) || (g.ncx == 2 && ox == 1);
+}
+
 template <int LPP>
 __device__ __forceinline__ double group_sum(double v)
 {
@@ -199,6 +208,7 @@ __device__ __forceinline__ void sweep(const Grid &g, const int *__restrict__ sta
     for (int ox = -1; ox <= 1; ++ox) {
         int col = cx + ox;
         if (g.periodic) {
+            if (duplicate_column(g, ox)) continue;
             if (col < 0) col += g.ncx;
             else if (col >= g.ncx) col -= g.ncx;
         } else if (col < 0 || col >= g.ncx) {
@@ -397,6 +407,7 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
             int col = cx + ox;
             bool ok = true;
             if (g.periodic) {
+                if (duplicate_column(g, ox)) ok = false;
                 if (col < 0) col += g.ncx;
                 else if (col >= g.ncx) col -= g.ncx;
             } else if (col < 0 || col >= g.ncx) {
@@ -779,6 +790,7 @@ __device__ __forceinline__ TileMap tile_ranges(const Grid &g, const FluidSet &s,
         int col = cx + ox;
         bool ok = true;
         if (g.periodic) {
+            if (duplicate_column(g, ox)) ok = false;
             if (col < 0) col += g.ncx;
             else if (col >= g.ncx) col -= g.ncx;
         } else if (col < 0 || col >= g.ncx) {

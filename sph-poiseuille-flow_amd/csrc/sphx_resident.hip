@@ -889,8 +889,9 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     y_extent(py, n_total, y_min, y_max);
     const double cs = 2.0 * prm->h + skin;
     Grid g{};
-    g.ncx = (int)std::floor(prm->DL / cs);
-    require(g.ncx >= 3, "SPH:Neighbor:param", "device path needs DL >= 6h (three periodic cell columns).");
+    // Any DL > 0 (the reference's grid is ceil(DL/2h) >= 1 columns plus ghost entries, neighbor.c:253-296): below three
+    // columns the sweeps visit each distinct column once (duplicate_column) and the fold picks the nearest image.
+    g.ncx = std::max(1, (int)std::floor(prm->DL / cs));
     g.ncy = (int)std::ceil((y_max - y_min + 1e-12) / cs) + 1;
     require((double)g.ncx * (double)g.ncy < 2.0e9, "SPH:Neighbor:param", "cell grid too large.");
     g.ncells = g.ncx * g.ncy;

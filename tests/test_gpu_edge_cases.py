@@ -120,9 +120,54 @@ def test_neighbour_list_overflow_is_reported(cfgmod, geom, capi):
         assert e.value.code == capi.SPHX_ERR_GRID
 
 
-def test_short_channel_rejected_with_reference_style_id(cfgmod, geom, mex):
-    prm = cfgmod.params_from_values(dp=0.1, DL=0.6)      # DL = 4.6 h < 6 h
-    parts = geom.init_particles(prm)
-    with pytest.raises(mex.MexError) as e:
-        mex.sph_neighbor_search_mex(parts["pos"], parts["n_fluid"], parts["n_total"], prm.h, prm.DL)
-    assert e.value.identifier == "SPH:Neighbor:param"
+def _nearest_image_pairs(parts, prm):
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    x, y = np.mod(parts["pos"][:, 0], prm.DL), parts["pos"][:, 1]
+    dx = x[:nf, None] - x[None, :]
+    dx = np.where(dx > 0.5 * prm.DL, dx - prm.DL, np.where(dx < -0.5 * prm.DL, dx + prm.DL, dx))
+    dy = y[:nf, None] - y[None, :]
+    r2 = dx * dx + dy * dy
+    ok = (r2 > 1e-24) & (r2 < (2 * prm.h) ** 2)
+    jj, ii = np.arange(nt)[None, :], np.arange(nf)[:, None]
+    ok &= (jj >= nf) | (jj > ii)
+    bi, bj = np.nonzero(ok)
+    return bi, bj, np.sqrt(r2[bi, bj])
+
+
+@pytest.mark.parametrize("DL", [0.7, 0.6])  # h = 0.13: 5.4 h and 4.6 h
+def test_two_column_channel_matches_oracle(cfgmod, geom, mex, capi, oracle, DL):
+    """4h <= DL < 6h: two cell columns, the left and the right neighbour column are the same one.  The reference finds
+    every partner once through seen_neighbor (neighbor.c:342,383); so must the device search -- and the resident step
+    built on it."""
+    dp = 0.1
+    prm, parts = make_case(cfgmod, geom, dp=dp, DL=DL, jitter=0.25, seed=9, developed=True)
+    assert 4 * prm.h <= prm.DL < 6 * prm.h, (prm.DL, prm.h)
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    a = canon_pairs(mex.sph_neighbor_search_mex(parts["pos"], nf, nt, prm.h, prm.DL))
+    b = canon_pairs(oracle.neighbor_search(parts["pos"], nf, nt, prm.h, prm.DL))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert_close(a[4], b[4], rtol=1e-13, atol=1e-15 * prm.DL, name="r")
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=4, enable_sort=False)
+    with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
+                      t_end=1e9) as ctx:
+        assert ctx.info()["n_cell_x"] == 2 and ctx.grid_policy()["rebuild_every"] == 1
+        ctx.advance(1e9, max_steps=4)
+        got = ctx.download()
+    for k in ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B"):
+        assert_close(got[k], ref[k], rtol=1e-9, atol_scale=1e-10, name=k)
+
+
+@pytest.mark.parametrize("n_cols_dp", [4, 2])
+def test_one_column_channel_gives_the_nearest_image_of_every_pair(cfgmod, geom, mex, n_cols_dp):
+    """DL < 4h (one cell column; at DL < 2h narrower than the kernel support): a pair can have two images within 2h.  The
+    reference keeps whichever its cell scan meets first; the device search keeps the nearest one -- a period shorter
+    than two kernel supports has no physical use, what matters is that the call is accepted (the reference accepts any
+    DL > 0) and well defined."""
+    dp = 0.1
+    prm, parts = make_case(cfgmod, geom, dp=dp, DL=n_cols_dp * dp, jitter=0.2, seed=4, developed=False)
+    assert prm.DL < 4 * prm.h
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    a = canon_pairs(mex.sph_neighbor_search_mex(parts["pos"], nf, nt, prm.h, prm.DL))
+    bi, bj, r = _nearest_image_pairs(parts, prm)
+    assert np.array_equal(a[0].astype(int) - 1, bi) and np.array_equal(a[1].astype(int) - 1, bj)
+    assert_close(a[4], r, rtol=1e-13, atol=1e-15, name="r")
