@@ -372,12 +372,13 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
                     const bool wall = (e & kWallBit) != 0;
                     const int k = e & (kWallBit - 1);
                     const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
+                    const double Volw = wall ? w.a[k].x : 0.0;  // requested with the position, not after the distance test
                     const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                         acc = true;
                         const double W = spline_W(ph.kc, r2 * rsqrt(r2));
-                        if (wall) s_ct += W * w.a[k].x;
+                        if (wall) s_ct += W * Volw;
                         else s_in += W;
                     }
                 }
