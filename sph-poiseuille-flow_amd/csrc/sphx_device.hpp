@@ -121,55 +121,60 @@ struct Mat2 {
     double m11, m12, m21, m22;
 };
 
-// B = w1 * pinv_reg(A) + w2 * I
+// Kernel-gradient-correction matrix from the moment matrix A (sph_physics_mex.c:321-366):
+//   P = (A^T A + eps I)^-1 A^T      Tikhonov-regularised pseudo-inverse (identity when A^T A + eps I is singular)
+//   B = lambda P + (1 - lambda) I   with lambda = det A / (det A + max(1 - det A, 0))  (0 when that denominator vanishes)
+// i.e. the full correction where the particle's support is complete (det A -> 1) and a fade to "no correction" where
+// it is truncated.  The thresholds (1e-20, 1e-12) and the order of the operations are the reference's: they decide
+// which branch a borderline particle takes.
 __device__ __forceinline__ Mat2 kgc_from_A(double a11, double a12, double a21, double a22)
 {
-    const double ata11 = a11 * a11 + a21 * a21 + kEpsReg;
-    const double ata12 = a11 * a12 + a21 * a22;
-    const double ata22 = a12 * a12 + a22 * a22 + kEpsReg;
-    const double det_m = ata11 * ata22 - ata12 * ata12;
-    double p11, p12, p21, p22;
-    if (fabs(det_m) < 1e-20) {
-        p11 = 1.0; p12 = 0.0; p21 = 0.0; p22 = 1.0;
-    } else {
-        const double im11 = ata22 / det_m, im12 = -ata12 / det_m, im22 = ata11 / det_m;
-        p11 = im11 * a11 + im12 * a12;
-        p12 = im11 * a21 + im12 * a22;
-        p21 = im12 * a11 + im22 * a12;
-        p22 = im12 * a21 + im22 * a22;
+    // normal matrix N = A^T A + eps I (symmetric: n11, n12, n22)
+    const double n11 = a11 * a11 + a21 * a21 + kEpsReg;
+    const double n12 = a11 * a12 + a21 * a22;
+    const double n22 = a12 * a12 + a22 * a22 + kEpsReg;
+    const double det_n = n11 * n22 - n12 * n12;
+    Mat2 P{1.0, 0.0, 0.0, 1.0};
+    if (!(fabs(det_n) < 1e-20)) {
+        // N^-1 = [n22 -n12; -n12 n11] / det_n, then P = N^-1 A^T
+        const double i11 = n22 / det_n, i12 = -n12 / det_n, i22 = n11 / det_n;
+        P.m11 = i11 * a11 + i12 * a12;
+        P.m12 = i11 * a21 + i12 * a22;
+        P.m21 = i12 * a11 + i22 * a12;
+        P.m22 = i12 * a21 + i22 * a22;
     }
     const double det_a = a11 * a22 - a12 * a21;
-    const double det_sqr = fmax(1.0 - det_a, 0.0);
-    const double denom = det_a + det_sqr;
-    double w1, w2;
-    if (fabs(denom) < 1e-12) { w1 = 0.0; w2 = 1.0; }
-    else { w1 = det_a / denom; w2 = det_sqr / denom; }
+    const double deficit = fmax(1.0 - det_a, 0.0);
+    const double total = det_a + deficit;
+    double lambda = 0.0, rest = 1.0;
+    if (!(fabs(total) < 1e-12)) { lambda = det_a / total; rest = deficit / total; }
     Mat2 B;
-    B.m11 = w1 * p11 + w2;
-    B.m12 = w1 * p12;
-    B.m21 = w1 * p21;
-    B.m22 = w1 * p22 + w2;
+    B.m11 = lambda * P.m11 + rest;
+    B.m12 = lambda * P.m12;
+    B.m21 = lambda * P.m21;
+    B.m22 = lambda * P.m22 + rest;
     return B;
 }
 
+// dissipation speed of the low-dissipation Riemann pressure (sph_physics_mex.c:1121-1129): three times the approach
+// speed of the pair along its axis, capped by the sound speed; zero for a separating pair
 __device__ __forceinline__ double riemann_beta(double un_l, double un_r, double c_f)
 {
-    double compression = un_l - un_r;
-    if (compression < 0.0) compression = 0.0;
-    return fmin(3.0 * compression, c_f);
+    double approach = un_l - un_r;
+    if (approach < 0.0) approach = 0.0;
+    return fmin(3.0 * approach, c_f);
 }
 
-// transport limiter: pos += coeff*h^2 * clamp(100|inc|^2/h^2,0,1) * inc
+// transport-velocity shift (sph_physics_mex.c:702-710): coeff h^2 inc, faded in by min(1, 100 |inc|^2 / h^2)
 __device__ __forceinline__ void transport_shift(double inc_x, double inc_y, double h, double coeff,
                                                 double &sx, double &sy)
 {
-    const double n2 = inc_x * inc_x + inc_y * inc_y;
-    double limiter = 100.0 * n2 / (h * h);
-    const double scale = coeff * h * h;
-    if (limiter > 1.0) limiter = 1.0;
-    if (limiter < 0.0) limiter = 0.0;
-    sx = scale * limiter * inc_x;
-    sy = scale * limiter * inc_y;
+    double fade = 100.0 * (inc_x * inc_x + inc_y * inc_y) / (h * h);
+    const double gain = coeff * h * h;
+    if (fade > 1.0) fade = 1.0;
+    if (fade < 0.0) fade = 0.0;
+    sx = gain * fade * inc_x;
+    sy = gain * fade * inc_y;
 }
 
 __device__ __forceinline__ double eos_pressure(double rho, double rho0, double p0)
