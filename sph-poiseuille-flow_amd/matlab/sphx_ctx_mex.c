@@ -4,6 +4,8 @@
  *   st = sphx_ctx_mex('advance', h, t_target, max_steps)        % struct: t, dt_last, dt_next, vmax, step, done
  *   [pos,vel,rho,p,drho_dt,force,force_prior,Vol,B] = sphx_ctx_mex('download', h)
  *   [tau_bottom, tau_top, n_pairs] = sphx_ctx_mex('monitor', h)
+ *   sphx_ctx_mex('prepare', h, n_steps)      % capture the graph an advance(h, t, n_steps) issued next replays
+ *   [replayed, eager, captured] = sphx_ctx_mex('graph_stats', h)
  *   sphx_ctx_mex('destroy', h)
  * cfg is the struct SPH_Poiseuille.m builds at :175-196 (fields DL, DH, dp, h, rho0, mu, c_f, p0, inv_sigma0,
  * gravity_g, transport_coeff, t_end, sort_interval).  NOT compiled in this repository (no MATLAB in the image);
@@ -70,6 +72,14 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         plhs[0] = mxCreateDoubleScalar(tb);
         if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(tt);
         if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(np);
+    } else if (strcmp(cmd, "prepare") == 0) {
+        ok(sphx_ctx_prepare_steps(handle(prhs[1]), (int64_t)mxGetScalar(prhs[2])));
+    } else if (strcmp(cmd, "graph_stats") == 0) {
+        int64_t a = 0, b = 0, g = 0;
+        ok(sphx_ctx_graph_stats(handle(prhs[1]), &a, &b, &g));
+        plhs[0] = mxCreateDoubleScalar((double)a);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar((double)b);
+        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar((double)g);
     } else if (strcmp(cmd, "destroy") == 0) {
         sphx_ctx_destroy(handle(prhs[1]));
         mexUnlock();
