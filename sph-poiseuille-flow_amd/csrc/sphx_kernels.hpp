@@ -89,6 +89,11 @@ struct Clock {
     int rebuild_now;             // 1: the re-binning kernels of this step run
     int pos_count;               // steps since the last re-binning
     int n_drift_rebuilds;        // re-binnings triggered by the drift bound (statistics)
+    // Whenever the loop stops (step budget used up, target reached, status, stale grid) the clock is also written to
+    // `pub`, a copy in pinned host memory: the host then needs no device-to-host copy to learn how a batch ended.
+    // seq counts the batches armed (k_prepare), so the host can tell a fresh copy from an old one.
+    long long seq;
+    Clock *pub;
 };
 
 // Everything a neighbour pass GATHERS per neighbour is stored as 16- or 32-byte records (position, velocity,
@@ -260,7 +265,9 @@ __global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_st
     const int go = loop_continues(c) ? 1 : 0;
     c.run[0] = q0 == 0 ? go : 0;  // constant indices: a dynamically indexed member forces the struct into scratch
     c.run[1] = q0 == 0 ? 0 : go;
+    c.seq += 1;
     *clk = c;
+    if (!go && c.pub) *c.pub = c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1248,6 +1255,7 @@ __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phy
     if (q == 0) c.run[1] = go;  // constant indices: c.run[1 - q] would force the whole struct into scratch memory --
     else c.run[0] = go;         // 120 bytes per lane of EVERY wave of pass E when the tail workgroup lives there
     *clk = c;
+    if (!go && c.pub) *c.pub = c;  // the batch ends here: tell the host (see Clock::pub)
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -108,6 +108,8 @@ struct sphx_ctx {
     DevBuf<Clock> clock;
     DevBuf<double> tau_part, tau_out;
     Clock *h_clock = nullptr;  // pinned
+    Clock *h_pub = nullptr;    // pinned + mapped: the device writes the clock here whenever the loop stops (Clock::pub)
+    long long host_seq = 0;    // batches armed so far (k_prepare launches), cf. Clock::seq
 
     FluidTmp tmp{};
     Walls walls{};
@@ -188,6 +190,7 @@ struct sphx_ctx {
         if (ev_computed) (void)hipEventDestroy(ev_computed);
         if (ev_received) (void)hipEventDestroy(ev_received);
         if (h_clock) (void)hipHostFree(h_clock);
+        if (h_pub) (void)hipHostFree(h_pub);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -454,6 +457,13 @@ void track_step(sphx_ctx *c)
     else c->pos += 1;
 }
 
+// arm the device clock for a batch (k_prepare) and count it (Clock::seq / sphx_ctx::host_seq)
+void arm_clock(sphx_ctx *c, double t_target, long long max_steps, int q0, const double *vmax_in)
+{
+    c->host_seq += 1;
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target, max_steps, q0, vmax_in);
+}
+
 int graph_slots(const sphx_ctx *c)
 {
     const int period = c->dyn ? 2 : 2 * c->rebuild_every;  // (cur, lay, pos) returns to itself after 2K steps
@@ -563,10 +573,28 @@ void set_epoch(sphx_ctx *c)
     c->prov_step = c->epoch_step;
 }
 
+// wait for the stream: poll for a while (a blocking wait costs ~10 us of wake-up latency, which a 20-step batch of a
+// small channel notices), then block
+void wait_stream(sphx_ctx *c)
+{
+    for (int k = 0; k < 20000; ++k) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) SPHX_HIP(e);
+        (void)hipGetLastError();
+    }
+    SPHX_HIP(hipStreamSynchronize(c->stream));
+}
+
 void read_clock(sphx_ctx *c)
 {
-    SPHX_HIP(hipMemcpyAsync(c->h_clock, c->clock.get(), sizeof(Clock), hipMemcpyDeviceToHost, c->stream));
-    SPHX_HIP(hipStreamSynchronize(c->stream));
+    wait_stream(c);
+    if (c->h_pub && c->h_pub->seq == c->host_seq) {
+        *c->h_clock = *c->h_pub;  // the device published the clock when the last batch stopped
+    } else {  // nothing armed since the last read, or the batch ran out of slots with the loop still going
+        SPHX_HIP(hipMemcpyAsync(c->h_clock, c->clock.get(), sizeof(Clock), hipMemcpyDeviceToHost, c->stream));
+        SPHX_HIP(hipStreamSynchronize(c->stream));
+    }
     c->timer.collect();
     // replay the bookkeeping of the steps that really executed since the last read
     const int64_t executed = (int64_t)c->h_clock->step - c->epoch_step;
@@ -621,6 +649,7 @@ void forced_rebuild(sphx_ctx *c)
     c->cur = 1 - q; c->lay = 1 - l; c->pos = 0;  // out_lay stays l
     c->h_clock->need_rebuild = 0;
     c->h_clock->drift = 0.0;
+    if (c->h_pub) { c->h_pub->need_rebuild = 0; c->h_pub->drift = 0.0; }  // (the published copy may be read again before the next batch)
     // cool-down (see slot_rebuilds): 16 steps, doubled while the next forced rebuild follows the previous cool-down
     // within two rebuild cycles
     const int64_t now = c->h_clock->step;
@@ -810,6 +839,14 @@ void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
     k.step = step0; k.steps_left = -1; k.run[0] = 0; k.run[1] = 0; k.status = 0; k.n = n;
     k.drift = 0.0; k.need_rebuild = 0;
     k.fresh = 1; k.rebuild_now = 0; k.pos_count = 0; k.n_drift_rebuilds = 0;
+    k.seq = 0;
+    if (!c->h_pub) SPHX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pub), sizeof(Clock), hipHostMallocMapped));
+    void *pub_dev = nullptr;
+    SPHX_HIP(hipHostGetDevicePointer(&pub_dev, c->h_pub, 0));
+    k.pub = static_cast<Clock *>(pub_dev);
+    *c->h_pub = k;
+    c->h_pub->seq = -1;  // nothing published yet
+    c->host_seq = 0;
     *c->h_clock = k;
     SPHX_HIP(hipMemcpyAsync(c->clock.get(), c->h_clock, sizeof(Clock), hipMemcpyHostToDevice, s));
     SPHX_HIP(hipStreamSynchronize(s));
@@ -1002,8 +1039,7 @@ SPHX_EXPORT int sphx_ctx_advance(sphx_ctx *c, double t_target, int64_t max_steps
     read_clock(c);  // steps enqueued with sphx_ctx_enqueue_steps may still be in flight
     for (int guard = 0; guard < 1000000; ++guard) {
         if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
-        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target,
-                           (long long)max_steps, c->cur, (const double *)nullptr);
+        arm_clock(c, t_target, (long long)max_steps, c->cur, (const double *)nullptr);
         // how many slots this call needs, from the unclipped dt; over-provision to whole graphs when unlimited
         const Clock &k = *c->h_clock;
         const double dt_est = host_dt_unclipped(c, k.vmax);
@@ -1046,8 +1082,7 @@ SPHX_EXPORT int sphx_ctx_enqueue_steps(sphx_ctx *c, int64_t n_steps)
     // no host sync here: if an earlier batch stopped early (end time, status, stale grid) the loop condition is
     // still false when k_prepare re-evaluates it, so every slot of this batch is a no-op; sphx_ctx_sync sorts
     // out the grid and takes the steps that are still owed
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end,
-                       (long long)n_steps, c->cur, (const double *)nullptr);
+    arm_clock(c, c->prm.t_end, (long long)n_steps, c->cur, (const double *)nullptr);
     enqueue_slots(c, n_steps, true);
     c->pending_target = std::max<int64_t>(c->pending_target, c->h_clock->step) + n_steps;
     return SPHX_OK;
@@ -1097,8 +1132,7 @@ SPHX_EXPORT int sphx_ctx_sync(sphx_ctx *c, sphx_status *status)
         // the batch stopped at a stale grid: take the steps still owed, in chunks (slots behind another stop
         // would be empty launches)
         const int64_t n = std::min(owed, c->chunk_slots);
-        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end, (long long)n,
-                           c->cur, (const double *)nullptr);
+        arm_clock(c, c->prm.t_end, (long long)n, c->cur, (const double *)nullptr);
         enqueue_slots(c, n, false);
         read_clock(c);
         if (!c->h_clock->need_rebuild) c->chunk_slots = std::min<int64_t>(4096, 2 * c->chunk_slots);
@@ -1603,8 +1637,7 @@ SPHX_EXPORT int sphx_slab_prepare(sphx_ctx *c, double t_target, int64_t max_step
 {
     SPHX_TRY
     require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target, (long long)max_steps,
-                       c->cur, vmax_global_dev);
+    arm_clock(c, t_target, (long long)max_steps, c->cur, vmax_global_dev);
     SPHX_HIP(hipGetLastError());
     return SPHX_OK;
     SPHX_CATCH
@@ -1929,8 +1962,7 @@ SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
     // arm the clock with the global max |v| of the current state
     slab_local_maxima(c);
     R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, st, c->clock.get(), c->phys, t_target, (long long)n_steps, c->cur,
-                       (const double *)vg);
+    arm_clock(c, t_target, (long long)n_steps, c->cur, (const double *)vg);
     if (skinned && !c->lists_ready) {
         slab_lists_out(c);
         ring(c->ids_s_[0].get(), c->ids_s_[1].get(), c->ids_r_[0].get(), c->ids_r_[1].get(), n_ids, ncclInt32);
@@ -2007,8 +2039,7 @@ SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int
         sphx_ctx *c = ctxs[r];
         wait_others(r, &sphx_ctx::ev_computed);
         max_of_all(c);
-        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, t_target, (long long)n_steps, c->cur,
-                           (const double *)c->vmax_g.get());
+        arm_clock(c, t_target, (long long)n_steps, c->cur, (const double *)c->vmax_g.get());
         if (skinned && !c->lists_ready) slab_lists_out(c);
     }
     done(&sphx_ctx::ev_received);
@@ -2146,8 +2177,7 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     hipEvent_t a = nullptr, b = nullptr;
     try {
         // arm run[cur] so the kernels execute; no step slot follows, so the clock does not advance
-        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(1), 0, c->stream, c->clock.get(), c->phys, c->prm.t_end, (long long)1,
-                           c->cur, (const double *)nullptr);
+        arm_clock(c, c->prm.t_end, (long long)1, c->cur, (const double *)nullptr);
         const FluidSet fs = c->view(c->cur, c->lay);
         const int dmode = c->dyn ? 3 : (c->skin > 0.0 ? (c->pos == 0 ? 1 : 2) : 0);
         launch_physics_any(c, c->cur, fs, c->tmp, 0, 0, dmode);  // make every temporary the timed kernel reads valid

@@ -331,14 +331,33 @@ def bench_main(args, rank, world, local_rank):
         else:
             pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
             start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
-        eng = HipSlabEngine(prm, parts, rank, world, local_rank, lanes_per_particle=args.lpp, t_end=1e9, pos=pos, vel=vel,
-                            native=native)
-        if native:
-            ident = [HipSlabEngine.unique_id(capi) if rank == 0 else None]
+        use_native, why_not = native, None
+        eng = None
+        if use_native:
+            # every rank must end up on the same path: a rank that cannot join the RCCL communicator (librccl missing,
+            # ncclCommInitRank refused ...) tells the others and all fall back to the caller-driven protocol
+            try:
+                ident = [HipSlabEngine.unique_id(capi) if rank == 0 else None]
+            except capi.SphxError as e:
+                ident, why_not = [None], str(e)
             dist.broadcast_object_list(ident, src=0)
-            eng.comm_init(ident[0])
+            if ident[0] is not None:
+                try:
+                    eng = HipSlabEngine(prm, parts, rank, world, local_rank, lanes_per_particle=args.lpp, t_end=1e9, pos=pos,
+                                        vel=vel, native=True)
+                    eng.comm_init(ident[0])
+                except capi.SphxError as e:
+                    why_not = str(e)
+            failed = torch.tensor([1 if (why_not or ident[0] is None) else 0], device=torch.device("cuda", local_rank))
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+            if int(failed.item()):
+                use_native = False
+                if eng is not None:
+                    eng.close()
+        if use_native:
             run = lambda n: (eng.run(n), eng.sync())[1]
         else:
+            eng = HipSlabEngine(prm, parts, rank, world, local_rank, lanes_per_particle=args.lpp, t_end=1e9, pos=pos, vel=vel)
             drv = SlabDriver(eng, RingExchange(rank, world))
             run = drv.run_steps
         if warmup > 0:
@@ -356,9 +375,11 @@ def bench_main(args, rank, world, local_rank):
         nt, lay = parts["n_total"], eng.layout()
         eng.close()
         alg = (528 * parts["n_fluid"] + 120 * parts["n_wall"]) * steps / seconds / 1e9
-        loop = ("native step loop in libsphx over RCCL: ncclSend/ncclRecv ring + one 8-byte ncclAllReduce(max) per step"
-                if native else f"Python step loop over torch.distributed[{dist.get_backend()}]"
-                               + (" (messages staged through host memory)" if dist.get_backend() != "nccl" else ""))
+        loop = ("native step loop in libsphx over RCCL: re-binning every 5th step, per step two ncclSend/ncclRecv rings "
+                "(state, list ids) + one 16-byte ncclAllReduce(max)"
+                if use_native else f"Python step loop over torch.distributed[{dist.get_backend()}], re-binning every step"
+                                   + (" (messages staged through host memory)" if dist.get_backend() != "nccl" else "")
+                                   + (f" -- native RCCL loop unavailable: {why_not}" if native and why_not else ""))
         return dict(value=nt * steps / seconds, ms_per_step=1e3 * seconds / steps, steps=steps, warmup=warmup,
                     scaling="strong" if strong else "weak",
                     workload=f"{name} x{world if not strong else 1}: dp={prm.dp}, DL={prm.DL}, DH={prm.DH}, "
