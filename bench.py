@@ -41,6 +41,9 @@ for _k in ("_build", "_walk", "_dyn"):  # pass A sweeping cells + recording the 
     BYTES_PER_WALL["k_density" + _k] = BYTES_PER_WALL["k_density"]
 BYTES_PER_FLUID["k_continuity_clock"] = BYTES_PER_FLUID["k_continuity"]  # pass E carrying the clock update
 BYTES_PER_WALL["k_continuity_clock"] = BYTES_PER_WALL["k_continuity"]
+# small channels: pass E of a step and pass A of the next one in one launch
+BYTES_PER_FLUID["k_continuity_density"] = BYTES_PER_FLUID["k_continuity"] + BYTES_PER_FLUID["k_density"]
+BYTES_PER_WALL["k_continuity_density"] = BYTES_PER_WALL["k_continuity"] + BYTES_PER_WALL["k_density"]
 STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
 
 

@@ -286,11 +286,12 @@ __device__ __forceinline__ int list_fluid_rows(int packed) { return packed >> 16
 
 // Prologue shared by the passes: everything whose address does not depend on the clock is requested
 // BEFORE the run flag is looked at, so the clock read overlaps the particle's own loads.
-#define SPHX_PASS_INDEX()                                                  \
-    const int blk = xcd_block(blockIdx.x, gridDim.x);                      \
+#define SPHX_PASS_INDEX_AT(bid, nblk)                                      \
+    const int blk = xcd_block((bid), (nblk));                              \
     const int tid = blk * kBlock + threadIdx.x;                            \
     const int i = tid / LPP, sub = tid % LPP;                              \
     const bool in_cap = i < t.cap
+#define SPHX_PASS_INDEX() SPHX_PASS_INDEX_AT((int)blockIdx.x, (int)gridDim.x)
 
 // ---------------------------------------------------------------------------------------------
 // pass A: candidate sweep -> neighbour list; number-density summation -> rho, Vol
@@ -299,11 +300,14 @@ __device__ __forceinline__ int list_fluid_rows(int packed) { return packed >> 16
 // ---------------------------------------------------------------------------------------------
 // MODE 0: sweep the cells, write the step's list.  MODE 1: same sweep, also write the superset list.
 // MODE 2: walk the superset list instead of the cells.
+// bid / nblk: the workgroup's index among the nblk workgroups of this pass (the fused launch k_continuity_density runs the
+// pass in a sub-range of its grid).  half: also write the half-step density / pressure (needs the step's dt; the fused
+// launch runs pass A of the NEXT step, whose dt is not known yet -- pass B completes the record there).
 template <int LPP, int MODE>
 __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
-                                             const FluidTmp &t, const Walls &w)
+                                             const FluidTmp &t, const Walls &w, int bid, int nblk, bool half)
 {
-    SPHX_PASS_INDEX();
+    SPHX_PASS_INDEX_AT(bid, nblk);
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int ci = in_cap ? s.cell[i] : 0;
     const bool lead = in_cap && sub == 0;  // the lane that finishes the particle
@@ -494,9 +498,17 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
         const double rho = density_from_sigma(ph.w0 + s_in, s_ct, m, ph.rho0, ph.inv_sigma0);
         double rhoh = rho + 0.5 * dt * drho_i;
         if (rhoh < 1e-10) rhoh = ph.rho0;
-        t.a[i] = make_double4(m / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho);
+        t.a[i] = half ? make_double4(m / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho) : make_double4(m / rho, 0.0, 0.0, rho);
         t.vol[i] = m / rho;
     }
+}
+
+// the half-step density / pressure of a particle (integration_1st's pre-pass, sph_physics_mex.c:857-862)
+__device__ __forceinline__ void half_state(const Phys &ph, double rho, double drho, double dt, double &rhoh, double &ph_)
+{
+    rhoh = rho + 0.5 * dt * drho;
+    if (rhoh < 1e-10) rhoh = ph.rho0;
+    ph_ = eos_pressure(rhoh, ph.rho0, ph.p0);
 }
 
 // cond_fresh (dynamic contexts launch both MODE 1 and MODE 2 on every step): -1 = always run, 1 = only on a fresh grid,
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
                                                     FluidSet s, FluidTmp t, Walls w, int cond_fresh)
 {
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
-    density_body<LPP, MODE>(clk, q, g, ph, s, t, w);
+    density_body<LPP, MODE>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -516,12 +528,16 @@ __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Gri
 // (mex/sph_physics_mex.c:239-366).  Fluid and wall neighbours contribute the same term (Vol_j of a wall
 // particle is m/rho0), so the walk does not branch.
 // ---------------------------------------------------------------------------------------------
+// finish_half: pass A of this step ran inside the previous step's fused launch and left {p_half, rho_half} open
 template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
-                                                FluidTmp t, Walls w)
+                                                FluidTmp t, Walls w, int finish_half)
 {
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const bool closes = finish_half && in_cap && sub == 0;
+    const double4 a_own = closes ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
+    const double drho_own = closes ? s.drho[i] : 0.0;
     const int nn_all = list_rows(t.nl_cnt[tid]);
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
     // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
@@ -557,6 +573,11 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
     if (active && sub == 0) {
         const Mat2 B = kgc_from_A(a11, a12, a21, a22);
         t.B[i] = make_double4(B.m11, B.m12, B.m21, B.m22);
+        if (finish_half) {
+            double rhoh, p_half;
+            half_state(ph, a_own.w, drho_own, clk->dt, rhoh, p_half);
+            t.a[i] = make_double4(a_own.x, p_half, rhoh, a_own.w);
+        }
     }
 }
 
@@ -1313,19 +1334,13 @@ __device__ __forceinline__ void continuity_tail(Clock *clk, int q, const Phys &p
 
 // tail: 1 = the launch has one workgroup more than the pass needs; it runs continuity_tail
 // WALK: the large-channel form of the walk (see the "_w" kernels): entries ahead, fluid / wall loops, fold hoisted
+// (bid, nb: this workgroup's index among the nb workgroups of the pass; c_*: the LDS tile arrays of the calling kernel)
 template <int LPP, bool WALK, int TILE>
-__global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
-                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail)
+__device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
+                                                const FluidTmp &t, const Walls &w, int do_hist, int tail, int bid, int nb,
+                                                double2 *c_pos, double2 *c_vel, double *c_vol)
 {
-    constexpr int kSlots = TILE > 0 ? TILE : 1;
-    __shared__ double2 c_pos[kSlots], c_vel[kSlots];
-    __shared__ double c_vol[kSlots];
-    const int nb = (int)gridDim.x - tail;
-    if (tail && (int)blockIdx.x == nb) {
-        continuity_tail(clk, q, ph, t, nb);
-        return;
-    }
-    const int blk = xcd_block(blockIdx.x, nb);
+    const int blk = xcd_block(bid, nb);
     const int tid = blk * kBlock + threadIdx.x;
     const int i = tid / LPP, sub = tid % LPP;
     const bool in_cap = i < t.cap;
@@ -1449,6 +1464,42 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
         else
             t.vpart[blk] = m;
     }
+}
+
+template <int LPP, bool WALK, int TILE>
+__global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
+                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail)
+{
+    constexpr int kSlots = TILE > 0 ? TILE : 1;
+    __shared__ double2 c_pos[kSlots], c_vel[kSlots];
+    __shared__ double c_vol[kSlots];
+    const int nb = (int)gridDim.x - tail;
+    if (tail && (int)blockIdx.x == nb) {
+        continuity_tail(clk, q, ph, t, nb);
+        return;
+    }
+    continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol);
+}
+
+// Small channels, steps that do not re-bin: pass E of this step and pass A of the NEXT step in one launch, side by
+// side.  Both depend only on pass CD (E on the kicked velocities, A on the new positions) and not on each other, and at
+// a few thousand particles the chip is mostly idle, so the launch takes as long as the longer of the two instead of
+// their sum plus a kernel boundary.  Workgroups [0, nb): pass E on state s with the step's list (t); [nb, 2 nb): pass A
+// on the new state s_next, walking the superset list, into the other list / record buffers (t_next) -- without the
+// half-step density and pressure, which need the next step's dt (the tail workgroup of this very launch computes it):
+// pass B of the next step closes that (k_kgc, finish_half); workgroup 2 nb: the clock (continuity_tail).
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_continuity_density(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
+                                                               Walls w, FluidSet s_next, FluidTmp t_next)
+{
+    const int nb = ((int)gridDim.x - 1) / 2;
+    const int b = (int)blockIdx.x;
+    if (b == 2 * nb) {
+        continuity_tail(clk, q, ph, t, nb);
+        return;
+    }
+    if (b < nb) continuity_body<LPP, false, 0>(clk, q, g, ph, s, t, w, 0, 1, b, nb, nullptr, nullptr, nullptr);
+    else density_body<LPP, 2>(clk, q, g, ph, s_next, t_next, w, b - nb, nb, false);
 }
 
 // standalone cell histogram (context creation, wall grid, slab steps): same binning as pass E

@@ -157,6 +157,15 @@ struct sphx_ctx {
     // Dynamic re-binning (large channels): the device decides when to re-bin, every step carries the (self-skipping)
     // re-binning kernels, the layout is rebuilt in place -> lay stays 0, only the state parity alternates
     bool dyn = false;
+    // Small channels: pass E of a step that does not re-bin and pass A of the next step share one launch
+    // (k_continuity_density).  The neighbour list and the {Vol, p, rho_h, rho} records then exist once per state parity:
+    // tmp_par[p] is `tmp` with the buffers of parity p; out_par = the parity of the last executed step (its Vol).
+    bool fuse_ea = false;
+    DevBuf<double4> fa2;
+    DevBuf<double> fvol2;
+    DevBuf<int> nl_idx2, nl_cnt2;
+    FluidTmp tmp_par[2] = {};
+    int out_par = 0, epoch_out_par = 0;
     bool walk_kernels = false;   // lanes_per_particle <= 8: passes B, CD, E run their large-channel ("_w") forms
     bool lds_tiles = false;      // ... and the force pass stages its tile's neighbourhood in LDS
     bool lds_tiles_be = false;   // ... KGC and continuity too (2 lanes per particle, channel larger than the Infinity Cache)
@@ -276,7 +285,7 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
     const dim3 ge(c->n_blocks_particles + tail);
     const char *name_e = tail ? "k_continuity_clock" : "k_continuity";
     if (!walk) {
-        if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
         if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
         if (!only || only == 4)
             launch(c, name_e, k_continuity<LPP, false, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
@@ -338,6 +347,21 @@ void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderA
            (const int *)c->perm.get(), ra);
 }
 
+template <int LPP>
+void launch_fused_ea_t(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn)
+{
+    launch(c, "k_continuity_density", k_continuity_density<LPP>, dim3(2 * c->n_blocks_particles + 1), dim3(kBlock), c->clock.get(),
+           q, c->grid, c->phys, s, t, c->walls, sn, tn);
+}
+void launch_fused_ea(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn)
+{
+    switch (c->lpp) {  // (fuse_ea contexts run the compact kernels: 16 or 32 lanes per particle)
+        case 16: launch_fused_ea_t<16>(c, q, s, t, sn, tn); break;
+        case 32: launch_fused_ea_t<32>(c, q, s, t, sn, tn); break;
+        default: throw Error(SPHX_ERR_STATE, "SPHX:Ctx:fuse", "internal: fused E|A launch at this lane count");
+    }
+}
+
 // One single-GPU step slot: state S[q], layout L[l].  rebuild: the step ends with re-binning into S[1-q], L[1-l]
 // (7 launches); otherwise the passes write the new state straight into S[1-q] and the layout stays (5 launches).
 void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
@@ -361,6 +385,17 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         if (dpart) dpart = c->vtile.get() + c->n_vtiles;
         n_red = c->n_vtiles;
     }
+    if (!rebuild && c->fuse_ea) {
+        // pass A of this step ran inside the previous step's last launch, unless this is the first step on a fresh grid
+        FluidTmp t = c->tmp_par[q], tn = c->tmp_par[1 - q];
+        const FluidSet o = c->view(1 - q, l);
+        t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+        if (pos == 0) launch_physics_any(c, q, s, t, 0, 1, 1);
+        launch_physics_any(c, q, s, t, 0, 2);
+        launch_physics_any(c, q, s, t, 0, 3);
+        launch_fused_ea(c, q, s, t, o, tn);
+        return;
+    }
     if (!rebuild) {
         FluidTmp t = c->tmp;
         const FluidSet o = c->view(1 - q, l);
@@ -376,7 +411,15 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
                (int *)nullptr, 0, (const int *)nullptr, dpart, 0, c->half_skin(), (int *)nullptr, c->vpart_reset(), 0);
         return;
     }
-    launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
+    if (c->fuse_ea) {  // re-binning step: pass A came with the previous step (or stands alone at pos 0), E has a launch of its own
+        const FluidTmp &t = c->tmp_par[q];
+        if (pos == 0) launch_physics_any(c, q, s, t, 1, 1, 1);
+        launch_physics_any(c, q, s, t, 1, 2);
+        launch_physics_any(c, q, s, t, 1, 3);
+        launch_physics_any(c, q, s, t, 1, 4);
+    } else {
+        launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
+    }
     pre_reduce();
     const FluidSet d = c->view(1 - q, 1 - l);
     if (!c->big_scan) {  // clock update and cell scan share one single-block kernel
@@ -452,6 +495,7 @@ void track_step(sphx_ctx *c)
     const bool rebuild = slot_rebuilds(c);
     c->prov_step += 1;
     c->out_lay = c->lay;  // outputs are stored in the layout the step ran in; after a rebuild tmp.src_of maps to it
+    c->out_par = c->cur;  // ... and (fuse_ea) in the record buffers of the step's state parity
     c->cur ^= 1;
     if (rebuild) { c->lay ^= 1; c->pos = 0; }
     else c->pos += 1;
@@ -570,6 +614,7 @@ void set_epoch(sphx_ctx *c)
 {
     c->epoch_step = c->h_clock->step;
     c->epoch_cur = c->cur; c->epoch_lay = c->lay; c->epoch_pos = c->pos; c->epoch_out_lay = c->out_lay;
+    c->epoch_out_par = c->out_par;
     c->prov_step = c->epoch_step;
 }
 
@@ -599,6 +644,7 @@ void read_clock(sphx_ctx *c)
     // replay the bookkeeping of the steps that really executed since the last read
     const int64_t executed = (int64_t)c->h_clock->step - c->epoch_step;
     c->cur = c->epoch_cur; c->lay = c->epoch_lay; c->pos = c->epoch_pos; c->out_lay = c->epoch_out_lay;
+    c->out_par = c->epoch_out_par;
     c->prov_step = c->epoch_step;
     if (executed > 0) {
         int64_t left = executed;
@@ -771,6 +817,16 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
                       c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get()};
+    // E|A fusion: small static-schedule channels on the compact kernels (the clock rides in the tail workgroup)
+    c->fuse_ea = c->tail_clock && c->lpp >= 16 && !std::getenv("SPHX_NO_FUSE_EA");
+    c->tmp_par[0] = c->tmp;
+    c->tmp_par[1] = c->tmp;
+    if (c->fuse_ea) {
+        c->fa2.alloc(cap); c->fvol2.alloc(cap); c->fa2.zero(c->stream); c->fvol2.zero(c->stream);
+        c->nl_idx2.alloc(stride * nl_cap); c->nl_cnt2.alloc(stride); c->nl_cnt2.zero(c->stream);
+        c->tmp_par[1].a = c->fa2.get(); c->tmp_par[1].vol = c->fvol2.get();
+        c->tmp_par[1].nl_idx = c->nl_idx2.get(); c->tmp_par[1].nl_cnt = c->nl_cnt2.get();
+    }
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
@@ -1194,7 +1250,7 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
     if (p) { unsort_o(c->p_out.get(), 1, 0, 0); fill_w(0, 0.0); out(p, 1); }
     if (force) { unsort_o(c->ff.get(), 2, 0, 0); unsort_o(c->ff.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force, 2); }
     if (force_prior) { unsort_o(c->ffp.get(), 2, 0, 0); unsort_o(c->ffp.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force_prior, 2); }
-    if (Vol) { unsort_o(c->fa.get(), 4, 0, 0); unsort_w(c->wa.get(), 4, 0, 0); out(Vol, 1); }
+    if (Vol) { unsort_o(c->tmp_par[c->fuse_ea ? c->out_par : 0].a, 4, 0, 0); unsort_w(c->wa.get(), 4, 0, 0); out(Vol, 1); }
     if (B) {
         for (int k = 0; k < 4; ++k) unsort_o(c->fB.get(), 4, k, k);
         fill_w(0, 1.0); fill_w(1, 0.0); fill_w(2, 0.0); fill_w(3, 1.0);
@@ -1219,7 +1275,8 @@ SPHX_EXPORT int sphx_ctx_monitor(sphx_ctx *c, double *tau_bottom, double *tau_to
             throw Error(SPHX_ERR_STATE, "SPHX:Ctx:monitor", "wall shear needs Vol/B of a completed step");
         const int nblk = c->n_blocks_flat;
         hipLaunchKernelGGL(k_wall_shear, dim3(nblk), dim3(kBlock), 0, s, (const Clock *)c->clock.get(), c->grid, c->phys, fs,
-                           c->tmp, c->walls, (c->dyn ? c->h_clock->fresh != 0 : c->out_lay != c->lay) ? 1 : 0, c->tau_part.get());
+                           c->tmp_par[c->fuse_ea ? c->out_par : 0], c->walls,
+                           (c->dyn ? c->h_clock->fresh != 0 : c->out_lay != c->lay) ? 1 : 0, c->tau_part.get());
         hipLaunchKernelGGL(k_tau_final, dim3(1), dim3(kScanBlock), 0, s, nblk, (const double *)c->tau_part.get(),
                            c->phys.DL, c->tau_out.get());
         double h[2];
@@ -2180,9 +2237,10 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         arm_clock(c, c->prm.t_end, (long long)1, c->cur, (const double *)nullptr);
         const FluidSet fs = c->view(c->cur, c->lay);
         const int dmode = c->dyn ? 3 : (c->skin > 0.0 ? (c->pos == 0 ? 1 : 2) : 0);
-        launch_physics_any(c, c->cur, fs, c->tmp, 0, 0, dmode);  // make every temporary the timed kernel reads valid
+        const FluidTmp &tt = c->tmp_par[c->fuse_ea ? c->cur : 0];  // (fuse_ea: the records / list of the current state parity)
+        launch_physics_any(c, c->cur, fs, tt, 0, 0, dmode);  // make every temporary the timed kernel reads valid
         SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, fs, c->tmp, 0, only, dmode);
+        for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, fs, tt, 0, only, dmode);
         SPHX_HIP(hipStreamEndCapture(c->stream, &g));
         SPHX_HIP(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
         SPHX_HIP(hipGraphLaunch(e, c->stream));  // warm
