@@ -845,11 +845,10 @@ __host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : 
 // (No LDS tile here: staging the candidate positions made this pass 10 % slower at 0.5 M and at 6 M particles -- it
 // gathers 16 bytes per candidate, too little for the staging to pay.)
 template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
-                                                      FluidTmp t, Walls w, int cond_fresh)
+__device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
+                                                  const FluidTmp &t, const Walls &w, int bid, int nblk, bool half)
 {
-    if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
-    SPHX_PASS_INDEX();
+    SPHX_PASS_INDEX_AT(bid, nblk);
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool lead = in_cap && sub == 0;
     const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
@@ -934,21 +933,33 @@ __global__ __launch_bounds__(kBlock) void k_density_w(const Clock *clk, int q, G
         const double rho = density_from_sigma(ph.w0 + s_in, s_ct, mass_i, ph.rho0, ph.inv_sigma0);
         double rhoh = rho + 0.5 * dt * drho_i;
         if (rhoh < 1e-10) rhoh = ph.rho0;
-        t.a[i] = make_double4(mass_i / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho);
+        t.a[i] = half ? make_double4(mass_i / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho)
+                      : make_double4(mass_i / rho, 0.0, 0.0, rho);
         t.vol[i] = mass_i / rho;
     }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+                                                      FluidTmp t, Walls w, int cond_fresh)
+{
+    if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
+    density_walk_body<LPP>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true);
 }
 
 // pass B (see k_kgc)
 template <int LPP, int TILE>
 __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
-                                                  FluidTmp t, Walls w)
+                                                  FluidTmp t, Walls w, int finish_half)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots];
     __shared__ double c_vol[kSlots];
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const bool closes = finish_half && in_cap && sub == 0;  // (see k_kgc)
+    const double4 a_own = closes ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
+    const double drho_own = closes ? s.drho[i] : 0.0;
     const int packed = t.nl_cnt[tid];
     const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
     if (!clk->run[q]) return;
@@ -1023,6 +1034,11 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     if (active && sub == 0) {
         const Mat2 B = kgc_from_A(a11, a12, a21, a22);
         t.B[i] = make_double4(B.m11, B.m12, B.m21, B.m22);
+        if (finish_half) {
+            double rhoh, p_half;
+            half_state(ph, a_own.w, drho_own, clk->dt, rhoh, p_half);
+            t.a[i] = make_double4(a_own.x, p_half, rhoh, a_own.w);
+        }
     }
 }
 
@@ -1490,16 +1506,31 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
 // pass B of the next step closes that (k_kgc, finish_half); workgroup 2 nb: the clock (continuity_tail).
 template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_continuity_density(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
-                                                               Walls w, FluidSet s_next, FluidTmp t_next)
+                                                               Walls w, FluidSet s_next, FluidTmp t_next, int with_tail)
 {
-    const int nb = ((int)gridDim.x - 1) / 2;
+    const int nb = ((int)gridDim.x - with_tail) / 2;  // (with_tail = 0: kernel timing, the clock must not advance)
     const int b = (int)blockIdx.x;
-    if (b == 2 * nb) {
+    if (with_tail && b == 2 * nb) {
         continuity_tail(clk, q, ph, t, nb);
         return;
     }
-    if (b < nb) continuity_body<LPP, false, 0>(clk, q, g, ph, s, t, w, 0, 1, b, nb, nullptr, nullptr, nullptr);
+    if (b < nb) continuity_body<LPP, false, 0>(clk, q, g, ph, s, t, w, 0, with_tail, b, nb, nullptr, nullptr, nullptr);
     else density_body<LPP, 2>(clk, q, g, ph, s_next, t_next, w, b - nb, nb, false);
+}
+
+// the same with the large-channel forms of the two passes (mid-size channels: 4-8 lanes per particle, clock in the tail)
+template <int LPP>
+__global__ __launch_bounds__(kBlock) void k_continuity_density_w(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
+                                                                 Walls w, FluidSet s_next, FluidTmp t_next, int with_tail)
+{
+    const int nb = ((int)gridDim.x - with_tail) / 2;  // (with_tail = 0: kernel timing, the clock must not advance)
+    const int b = (int)blockIdx.x;
+    if (with_tail && b == 2 * nb) {
+        continuity_tail(clk, q, ph, t, nb);
+        return;
+    }
+    if (b < nb) continuity_body<LPP, true, 0>(clk, q, g, ph, s, t, w, 0, with_tail, b, nb, nullptr, nullptr, nullptr);
+    else density_walk_body<LPP>(clk, q, g, ph, s_next, t_next, w, b - nb, nb, false);
 }
 
 // standalone cell histogram (context creation, wall grid, slab steps): same binning as pass E

@@ -293,8 +293,8 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
         // LDS tiles (tile_ranges): the force pass always; KGC and continuity where measured to pay (lds_tiles_be)
         constexpr int T = tile_slots(LPP);
         if (!only || only == 2) {
-            if (c->lds_tiles_be) launch(c, "k_kgc", k_kgc_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
-            else launch(c, "k_kgc", k_kgc_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+            if (c->lds_tiles_be) launch(c, "k_kgc", k_kgc_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
+            else launch(c, "k_kgc", k_kgc_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
         }
         if (!only || only == 3) {
             if (c->lds_tiles) launch(c, "k_forces", k_forces_w<LPP, (LPP <= 2 ? 320 : T)>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
@@ -348,16 +348,26 @@ void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderA
 }
 
 template <int LPP>
-void launch_fused_ea_t(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn)
+void launch_fused_ea_t(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail)
 {
-    launch(c, "k_continuity_density", k_continuity_density<LPP>, dim3(2 * c->n_blocks_particles + 1), dim3(kBlock), c->clock.get(),
-           q, c->grid, c->phys, s, t, c->walls, sn, tn);
+    launch(c, "k_continuity_density", k_continuity_density<LPP>, dim3(2 * c->n_blocks_particles + tail), dim3(kBlock),
+           c->clock.get(), q, c->grid, c->phys, s, t, c->walls, sn, tn, tail);
 }
-void launch_fused_ea(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn)
+template <int LPP>
+void launch_fused_ea_w(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail)
 {
-    switch (c->lpp) {  // (fuse_ea contexts run the compact kernels: 16 or 32 lanes per particle)
-        case 16: launch_fused_ea_t<16>(c, q, s, t, sn, tn); break;
-        case 32: launch_fused_ea_t<32>(c, q, s, t, sn, tn); break;
+    launch(c, "k_continuity_density", k_continuity_density_w<LPP>, dim3(2 * c->n_blocks_particles + tail), dim3(kBlock),
+           c->clock.get(), q, c->grid, c->phys, s, t, c->walls, sn, tn, tail);
+}
+// tail = 0: without the clock workgroup (kernel timing)
+void launch_fused_ea(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail = 1)
+{
+    switch (c->lpp) {  // 16 / 32 lanes per particle: the compact kernels; fewer: their large-channel forms
+        case 2: launch_fused_ea_w<2>(c, q, s, t, sn, tn, tail); break;
+        case 4: launch_fused_ea_w<4>(c, q, s, t, sn, tn, tail); break;
+        case 8: launch_fused_ea_w<8>(c, q, s, t, sn, tn, tail); break;
+        case 16: launch_fused_ea_t<16>(c, q, s, t, sn, tn, tail); break;
+        case 32: launch_fused_ea_t<32>(c, q, s, t, sn, tn, tail); break;
         default: throw Error(SPHX_ERR_STATE, "SPHX:Ctx:fuse", "internal: fused E|A launch at this lane count");
     }
 }
@@ -818,7 +828,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
                       c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get()};
     // E|A fusion: small static-schedule channels on the compact kernels (the clock rides in the tail workgroup)
-    c->fuse_ea = c->tail_clock && c->lpp >= 16 && !std::getenv("SPHX_NO_FUSE_EA");
+    c->fuse_ea = c->tail_clock && (c->lpp >= 16 || (c->walk_kernels && !c->lds_tiles_be && c->lpp >= 2)) && !std::getenv("SPHX_NO_FUSE_EA");
     c->tmp_par[0] = c->tmp;
     c->tmp_par[1] = c->tmp;
     if (c->fuse_ea) {
@@ -966,7 +976,9 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // by ~10 %, the scatter/reorder kernels run on every fifth step only).
     // With the superset list: K = 5 / 8 / 10 give 24.9 / 24.3 / 24.1 us/step at 5 k particles (fewer rebuild
     // launches per step) but 2443 / 2490 / 2488 at 6 M (longer superset lists) -> 8 for small channels, 5 otherwise.
-    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 8 : 5);
+    // Round 2 (pass E and the next pass A share a launch: a step is 3 launches, a re-binning step 6): 5 k particles,
+    // K = 8 / 12 / 16 / 24 / 32 -> 21.1 / 19.95 / 19.6 / 19.6 / 19.4 us/step, the 20 s run's L2 0.85 / 0.85 / 0.80 / 0.90 % -> 16.
+    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 16 : 5);
     const double d_step = 0.035 * prm->h;
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
     if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
@@ -2224,7 +2236,8 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     else if (n == "k_kgc") only = 2;
     else if (n == "k_forces") only = 3;
     else if (n == "k_continuity" || n == "k_continuity_clock") only = 4;
-    require(only != 0, "SPHX:Ctx:kernel", "time_kernel knows k_density, k_kgc, k_forces, k_continuity");
+    else if (n == "k_continuity_density" && c->fuse_ea) only = 5;  // pass E and the next pass A in one launch
+    require(only != 0, "SPHX:Ctx:kernel", "time_kernel knows k_density, k_kgc, k_forces, k_continuity (and k_continuity_density)");
     read_clock(c);
     if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
     const bool prof = c->profiling;
@@ -2240,7 +2253,16 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         const FluidTmp &tt = c->tmp_par[c->fuse_ea ? c->cur : 0];  // (fuse_ea: the records / list of the current state parity)
         launch_physics_any(c, c->cur, fs, tt, 0, 0, dmode);  // make every temporary the timed kernel reads valid
         SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int k = 0; k < reps; ++k) launch_physics_any(c, c->cur, fs, tt, 0, only, dmode);
+        for (int k = 0; k < reps; ++k) {
+            if (only == 5) {  // (writes the other parity's list / records and the other state's drho: all rewritten by the next step)
+                FluidTmp te = tt;
+                const FluidSet o = c->view(1 - c->cur, c->lay);
+                te.posn = o.pos; te.veln = o.vel; te.drhon = o.drho;
+                launch_fused_ea(c, c->cur, fs, te, o, c->tmp_par[1 - c->cur], 0);
+            } else {
+                launch_physics_any(c, c->cur, fs, tt, 0, only, dmode);
+            }
+        }
         SPHX_HIP(hipStreamEndCapture(c->stream, &g));
         SPHX_HIP(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
         SPHX_HIP(hipGraphLaunch(e, c->stream));  // warm
