@@ -978,7 +978,10 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // launches per step) but 2443 / 2490 / 2488 at 6 M (longer superset lists) -> 8 for small channels, 5 otherwise.
     // Round 2 (pass E and the next pass A share a launch: a step is 3 launches, a re-binning step 6): 5 k particles,
     // K = 8 / 12 / 16 / 24 / 32 -> 21.1 / 19.95 / 19.6 / 19.6 / 19.4 us/step, the 20 s run's L2 0.85 / 0.85 / 0.80 / 0.90 % -> 16.
-    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 16 : 5);
+    // 20 k - 250 k particles, K = 5 / 8 / 12 / 16: 28.8 / 27.6 / 27.1 / 27.8 us/step at 21 k, 49.8 / 48.7 / 49.1 / 49.4 at 65 k,
+    // 79.5 / 72.1 / 72.6 / 74.8 at 130 k, 142 / 118 / 119 / 121 at 250 k (K = 5: its thin skin forces rebuilds + cool-downs) -> 8;
+    // 0.5 M: 189 / 192 at K = 5 / 8, 6 M: 2 201 / 2 262 -> 5.
+    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 16 : (nf <= 300000 ? 8 : 5));
     const double d_step = 0.035 * prm->h;
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
     if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
