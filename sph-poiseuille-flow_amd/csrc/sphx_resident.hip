@@ -121,7 +121,8 @@ struct sphx_ctx {
     // ONE graph whatever phase it was entered at; exact-length batches (sphx_ctx_enqueue_steps, advance with
     // max_steps -- a caller logging every 20 steps) get a graph per (phase, length), captured the first time that
     // combination comes up (or ahead of time by sphx_ctx_prepare_steps).
-    std::map<std::array<int, 4>, hipGraphExec_t> graphs;
+    struct CachedGraph { hipGraphExec_t exec = nullptr; bool launched = false; };
+    std::map<std::array<int, 4>, CachedGraph> graphs;
     int64_t slots_replayed = 0, slots_eager = 0, graphs_captured = 0;
     int64_t chunk_slots = 128;   // slots enqueued between two host looks at the clock (adaptive, see advance)
     bool profiling = false;
@@ -185,7 +186,7 @@ struct sphx_ctx {
     void drop_graph()
     {
         for (auto &kv : graphs)
-            if (kv.second) (void)hipGraphExecDestroy(kv.second);
+            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         graphs.clear();
     }
 
@@ -528,7 +529,7 @@ constexpr int kMinGraphSlots = 4;    // shorter exact batches are launched eager
 constexpr size_t kMaxGraphs = 96;    // cache bound: 2 * 2 * K phases for a caller with one cadence, K <= 16 in practice
 
 // the graph of `n` step slots entered at phase (cur, lay, pos) of the static schedule (dynamic contexts: only cur matters)
-hipGraphExec_t get_graph(sphx_ctx *c, int cur, int lay, int pos, int n)
+sphx_ctx::CachedGraph &get_graph(sphx_ctx *c, int cur, int lay, int pos, int n)
 {
     const std::array<int, 4> key{cur, c->dyn ? 0 : lay, c->dyn ? 0 : pos, n};
     auto it = c->graphs.find(key);
@@ -565,9 +566,10 @@ hipGraphExec_t get_graph(sphx_ctx *c, int cur, int lay, int pos, int n)
     const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     SPHX_HIP(e);
-    c->graphs[key] = exec;
+    sphx_ctx::CachedGraph &g_new = c->graphs[key];
+    g_new.exec = exec;
     c->graphs_captured += 1;
-    return exec;
+    return g_new;
 }
 
 // Enqueue `slots` step slots from the current (cur, lay, pos); slots that find run[q]==0 are no-ops.  Whole graphs
@@ -591,15 +593,20 @@ void enqueue_slots(sphx_ctx *c, int64_t slots, bool exact_tail, bool capture_onl
             else if (exact_tail && left >= kMinGraphSlots) n = (int)left;
         }
         if (n > 0) {
-            hipGraphExec_t exec = get_graph(c, c->cur, c->lay, c->pos, n);
+            sphx_ctx::CachedGraph &cg = get_graph(c, c->cur, c->lay, c->pos, n);
             if (capture_only) {
                 // First replays are slow (~4 us per step slot on ROCm 7.2: the executable graph is set up on the device
-                // at its first launch, hipGraphUpload does not take that over): replay it once now with the clock
-                // disarmed (k_disarm, see sphx_ctx_prepare_steps), so every kernel of every slot returns at once and
-                // nothing changes.
-                SPHX_HIP(hipGraphLaunch(exec, c->stream));
+                // at its first launch, hipGraphUpload does not take that over): a graph that has never run is replayed
+                // once now with the clock disarmed (k_disarm, see sphx_ctx_prepare_steps), so every kernel of every slot
+                // returns at once and nothing changes.  Small channels only: there a step is ~20 us; on millions of
+                // particles a first replay is noise and an idle pass over the arrays is not free.
+                if (!cg.launched && c->n_blocks_particles <= 8192) {
+                    SPHX_HIP(hipGraphLaunch(cg.exec, c->stream));
+                    cg.launched = true;
+                }
             } else {
-                SPHX_HIP(hipGraphLaunch(exec, c->stream));
+                SPHX_HIP(hipGraphLaunch(cg.exec, c->stream));
+                cg.launched = true;
                 c->slots_replayed += n;
             }
             for (int k = 0; k < n; ++k) track_step(c);
