@@ -1570,9 +1570,10 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
         }
     }
     const int n_local = (int)hf.x.size(), nw_local = (int)hw.x.size();
-    // capacities: message = (H+2) columns at twice the mean column load; arrays = window at 1.5x + messages
+    // capacities: a message carries the H boundary columns plus what crossed in one step -- (H+1) columns at 1.3x the mean
+    // column load (the whole buffer travels every step: 1 + 7 cap doubles per neighbour; overflow raises SPHX_ERR_GRID)
     const double per_col = (double)n_fluid / ncx_g;
-    c->msg_cap = (int)(2.0 * (H + 2) * per_col) + 1024;
+    c->msg_cap = (int)(1.3 * (H + 1) * per_col) + 1024;
     // (every kernel is launched for `cap` particles: slack costs time -- 15 % headroom over the initial population of this
     // weakly compressible flow; an overflow raises SPHX_ERR_GRID on the device, never a silent loss)
     const int cap = (int)(1.15 * std::max<double>(n_local, per_col * g.ncx)) + 2 * c->msg_cap + 1024;
