@@ -2,10 +2,11 @@
 //
 // One time step of SPH_Poiseuille.m:250-292 (density_correction -> viscous_force + gravity ->
 // transport_correction -> verlet_time_step -> integration_verlet -> periodic wrap -> neighbour
-// rebuild) is the kernel chain
-//     k_density -> k_kgc -> k_forces -> k_continuity -> k_clock_scan [-> k_scatter -> k_reorder]
-// with no host round trip; the bracketed re-binning runs on every K-th step only.  Design (long form in
-// DESIGN.md):
+// rebuild) is four neighbour passes with no host round trip,
+//     A k_density (list + density)  ->  B k_kgc  ->  CD k_forces  ->  E k_continuity (+ clock)
+// followed on every K-th step by the re-binning chain k_clock_scan -> k_scatter -> k_reorder.  On small channels pass E
+// of a step and pass A of the next one share a launch (k_continuity_density): 3 launches per step.  Design (long form
+// in DESIGN.md):
 //   * particles are sorted by cell, cell id = cx*ncy + cy (y fastest): the 3x3 neighbourhood of a cell is
 //     three contiguous index ranges and an x-slab of the channel is one contiguous range; everything a
 //     pass gathers per neighbour is a 16- or 32-byte record (double2 pos / vel, double4 {Vol,p,rho_h,rho},
@@ -16,23 +17,24 @@
 //     the same {1e-24 < r^2 < (2h)^2} (:368).  A slab of a multi-GPU run uses the same kernels on an
 //     open (non-periodic) window of columns;
 //   * cell skin: between two re-binnings the layout is frozen, sweeps are centred on the cell a particle
-//     was binned into, and the clock stops the loop before any particle is further than skin/2 from where
-//     it was binned (then the host re-bins and resumes) -- see Clock::drift, FluidSet::cell / posb;
-//   * k_density records the accepted neighbours (fluid and wall) of the step in a lane-major index list;
+//     was binned into, and the clock stops the loop (or, large channels and slabs: re-bins by itself) before any
+//     particle is further than skin/2 from where it was binned -- see Clock::drift, FluidSet::cell / posb;
+//   * pass A records the accepted neighbours (fluid first, then wall) of the step in a lane-major index list;
 //     the other three passes walk that list (all lanes busy, no cut-off branch, no cell lookups) -- the
 //     geometry is frozen for the step exactly as in the reference, which reuses dx,dy,r,W,dW of the pair
 //     list built at the end of the previous step.  The first step after a re-binning also records every
 //     pair within 2h+skin (superset list); the other steps of the cycle walk that instead of the cells;
 //   * every pair sum is a per-particle gather (each fluid-fluid update of mex/sph_physics_mex.c is
 //     symmetric under i<->j): no atomics in the physics, bitwise reproducible run to run;
-//   * LPP lanes of a wavefront share one particle's ring and combine with __shfl_xor (wave64);
-//   * at a few thousand particles a pass is a chain of dependent memory round trips: every pass requests
-//     its own-particle data, its list row count and its first list rows before it waits for the run flag;
+//   * LPP lanes of a wavefront share one particle's ring and combine with __shfl_xor (wave64): 32 / 16 at a few thousand
+//     particles (compact kernels: a pass is a chain of dependent memory round trips, every pass requests its
+//     own-particle data, its list row count and its first list rows before it waits for the run flag), 8 / 4 / 2 above
+//     (the "_w" forms: list entries three rows ahead, fluid / wall loops, LDS tiles of the neighbourhood);
 //   * dt, t, the step counter, the particle count and the stop test live in a device-side clock so
-//     steps can be captured into a hipGraph and replayed.  Small channels: the clock update of a non-re-binning
-//     step rides in a tail workgroup of pass E (continuity_tail).  Large channels ("dynamic" contexts): the clock
-//     kernel also decides when to re-bin and the re-binning kernels of every step skip themselves otherwise
-//     (slot_active, clock_step).
+//     steps can be captured into a hipGraph and replayed.  Small channels: the clock update rides in a tail workgroup of
+//     the last launch of a step (continuity_tail).  Large channels ("dynamic" contexts) and slabs: the clock also decides
+//     when to re-bin and the re-binning kernels of every step skip themselves otherwise (slot_active, clock_step);
+//   * x-slabs (multi-GPU): k_slab_* at the end of this file.
 #pragma once
 #include <type_traits>
 
