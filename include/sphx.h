@@ -144,7 +144,15 @@ typedef struct sphx_params {
     int32_t sort_interval;  /* kept for signature parity; the device keeps cell order (see rebuild_every) */
     int32_t lanes_per_particle; /* 0 = auto; 1,2,4,8,16,32: lanes cooperating on one neighbour ring */
     int32_t steps_per_graph;    /* 0 = auto; steps captured per hipGraph replay (even)               */
-    int32_t reserved;           /* must be 0                                                         */
+    int32_t dual_rate;          /* 0 / 1 = the reference's single-rate loop (SPH_Poiseuille.m:250-292, the parity path).
+                                   2..4 = opt-in dual-rate loop for small channels (<= ~30 k fluid particles, 16 / 32
+                                   lanes per particle): one step slot is an OUTER step -- density summation, KGC, viscous
+                                   force, transport shift once -- of up to dual_rate acoustic sub-steps of pressure /
+                                   continuity.  The count is fixed per context: as many acoustic steps as fit into the
+                                   viscous / body-force step (1 on fine channels, which are viscous-limited, and on
+                                   contexts that are not eligible; sphx_ctx_substeps reports it).  Not reference
+                                   behaviour: validated against the analytic profile only (2 sub-steps reproduce the
+                                   single-rate L2 and wall shear at dp = 0.05 / 0.025 / 0.02; 4 is noisier at dp = 0.05). */
     int32_t rebuild_every;      /* 0 = auto; K >= 1: particles are re-binned into cells every K-th step; in
                                    between, sweeps are centred on the cell a particle was binned into and
                                    the cells carry a skin (results do not depend on K beyond summation
@@ -226,6 +234,10 @@ int sphx_ctx_grid_policy(sphx_ctx *ctx, int *rebuild_every, double *skin, int64_
 
 /* The launch shape the context chose (lanes cooperating per particle, steps per hipGraph replay). */
 int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph);
+
+/* Inner sub-steps per step slot: 1 unless sphx_params::dual_rate asked for the dual-rate loop and the context is
+ * eligible.  With n_inner > 1 a "step" of sphx_status / max_steps is an outer step (t advances by n_inner * dt_last). */
+int sphx_ctx_substeps(sphx_ctx *ctx, int *n_inner);
 
 /* Global particle counts and the cell grid the context built. */
 int sphx_ctx_info(sphx_ctx *ctx, int *n_fluid, int *n_wall, int *n_cell_x, int *n_cell_y);

@@ -30,7 +30,7 @@ class SphxParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("DL", "DH", "dp", "h", "rho0", "mu", "c_f", "p0", "inv_sigma0",
                                            "gravity_g", "transport_coeff", "t_end")] + \
                [("sort_interval", C.c_int32), ("lanes_per_particle", C.c_int32),
-                ("steps_per_graph", C.c_int32), ("reserved", C.c_int32), ("rebuild_every", C.c_int32),
+                ("steps_per_graph", C.c_int32), ("dual_rate", C.c_int32), ("rebuild_every", C.c_int32),
                 ("dynamic_rebin", C.c_int32), ("skin_h", C.c_double)]
 
 
@@ -50,7 +50,7 @@ EXPORTS = [
     "sphx_ctx_create", "sphx_ctx_destroy", "sphx_ctx_advance", "sphx_ctx_enqueue_steps", "sphx_ctx_sync",
     "sphx_ctx_prepare_steps", "sphx_ctx_graph_stats",
     "sphx_ctx_download", "sphx_ctx_monitor", "sphx_ctx_neighbor_list", "sphx_ctx_profile_enable",
-    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_grid_policy", "sphx_ctx_time_kernel",
+    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_substeps", "sphx_ctx_grid_policy", "sphx_ctx_time_kernel",
     "sphx_slab_create", "sphx_slab_layout", "sphx_slab_local_vmax", "sphx_slab_prepare", "sphx_slab_compute",
     "sphx_slab_finish", "sphx_slab_sync", "sphx_slab_snapshot", "sphx_comm_unique_id", "sphx_slab_comm_init",
     "sphx_slab_comm_destroy", "sphx_slab_run", "sphx_slab_group_run",
@@ -100,13 +100,13 @@ def set_device(dev: int) -> None:
 
 
 def make_params(prm, t_end=None, transport_coeff=None, lanes_per_particle=0, steps_per_graph=0, rebuild_every=0,
-                skin_h=0.0, dynamic_rebin=0) -> SphxParams:
+                skin_h=0.0, dynamic_rebin=0, dual_rate=0) -> SphxParams:
     return SphxParams(DL=prm.DL, DH=prm.DH, dp=prm.dp, h=prm.h, rho0=prm.rho0, mu=prm.mu, c_f=prm.c_f,
                       p0=prm.p0, inv_sigma0=prm.inv_sigma0, gravity_g=prm.gravity_g,
                       transport_coeff=prm.transport_coeff if transport_coeff is None else transport_coeff,
                       t_end=prm.t_end if t_end is None else t_end, sort_interval=int(prm.sort_interval),
                       lanes_per_particle=int(lanes_per_particle), steps_per_graph=int(steps_per_graph),
-                      reserved=0, rebuild_every=int(rebuild_every), dynamic_rebin=int(dynamic_rebin), skin_h=float(skin_h))
+                      dual_rate=int(dual_rate), rebuild_every=int(rebuild_every), dynamic_rebin=int(dynamic_rebin), skin_h=float(skin_h))
 
 
 class Context:
@@ -114,11 +114,11 @@ class Context:
 
     def __init__(self, prm, n_fluid, n_total, pos, vel, drho_dt, mass, wall_vel, t0=0.0, step0=0,
                  t_end=None, transport_coeff=None, lanes_per_particle=0, steps_per_graph=0, rebuild_every=0,
-                 skin_h=0.0, dynamic_rebin=0):
+                 skin_h=0.0, dynamic_rebin=0, dual_rate=0):
         self._h = C.c_void_p()
         self.n_fluid, self.n_total = int(n_fluid), int(n_total)
         self.params = make_params(prm, t_end, transport_coeff, lanes_per_particle, steps_per_graph, rebuild_every,
-                                  skin_h, dynamic_rebin)
+                                  skin_h, dynamic_rebin, dual_rate)
         pos, vel, wall_vel = f64(pos), f64(vel), f64(wall_vel)
         drho_dt, mass = f64(drho_dt), f64(mass)
         assert pos.shape == (n_total, 2) and vel.shape == (n_total, 2) and wall_vel.shape == (n_total, 2)
@@ -197,6 +197,12 @@ class Context:
         a, b = C.c_int(0), C.c_int(0)
         check(lib().sphx_ctx_tuning(self._h, C.byref(a), C.byref(b)))
         return dict(lanes_per_particle=a.value, steps_per_graph=b.value)
+
+    def substeps(self) -> int:
+        """Inner sub-steps per step slot (1 = the reference's single-rate loop, see sphx_params.dual_rate)."""
+        n = C.c_int(0)
+        check(lib().sphx_ctx_substeps(self._h, C.byref(n)))
+        return n.value
 
     def time_kernel(self, name, reps=200) -> float:
         ms = C.c_double(0.0)

@@ -96,6 +96,11 @@ struct Clock {
     // seq counts the batches armed (k_prepare), so the host can tell a fresh copy from an old one.
     long long seq;
     Clock *pub;
+    // Opt-in dual-rate loop (sphx_params::dual_rate, the outer / inner stepping the reference's README describes): a step
+    // slot is one OUTER step of n_in inner sub-steps of length dt -- density, KGC, viscous force and transport shift once,
+    // pressure / continuity n_in times.  n_in = 1 is the reference's loop (SPH_Poiseuille.m:250-292), the parity path.
+    int n_in;
+    int pad2;
 };
 
 // Everything a neighbour pass GATHERS per neighbour is stored as 16- or 32-byte records (position, velocity,
@@ -234,6 +239,12 @@ __device__ __forceinline__ double next_dt(const Clock &c, const Phys &ph)
     const double dt_acoustic = 0.25 * h / fmax(ph.c_f + c.vmax, 1e-12);
     const double dt_viscous = 0.125 * h * h / fmax(ph.nu, 1e-12);
     const double dt_body = 0.25 * sqrt(h / fmax(fabs(ph.g), 1e-12));
+    if (c.n_in > 1) {
+        // outer step by the advection / viscous / body-force scales, at most n_in acoustic steps long; dt is the inner step
+        const double dt_adv = 0.25 * h / fmax(c.vmax, 1e-12);
+        const double Dt = fmin(fmin(fmin(dt_adv, dt_viscous), fmin(dt_body, remain)), c.n_in * dt_acoustic);
+        return fmax(Dt / c.n_in, 1e-12);
+    }
     const double dt = fmin(fmin(dt_acoustic, dt_viscous), fmin(dt_body, remain));
     return fmax(dt, 1e-12);
 }
@@ -591,9 +602,12 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
 // e, dW, B_i+B_j; the wall entries are visited a second time because the wall pressure needs the
 // complete viscous+gravity force of the particle first (p_wall uses force_prior_i, :931-934).
 // ---------------------------------------------------------------------------------------------
+// later = 1 (dual-rate loop, inner sub-steps after the first): the pressure part only -- viscous force and gravity
+// are those of the first sub-step (t.fp), there is no transport shift, the particle moves on from t.posn; pair geometry
+// stays that of the start of the outer step (s.pos), velocities are the latest ones (s.vel = the previous sub-step's).
 template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
-                                                   FluidTmp t, Walls w)
+                                                   FluidTmp t, Walls w, int later)
 {
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
@@ -610,6 +624,8 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     const int e_row3 = LPP <= 8 ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     const bool tracked = s.posb != nullptr;
     const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
+    const double2 fp_own = (later && in_cap) ? t.fp[i] : make_double2(0.0, 0.0);
+    const double2 p_now = (later && in_cap && sub == 0) ? t.posn[i] : make_double2(0.0, 0.0);
     const double dt = clk->dt;
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
@@ -636,13 +652,15 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
                 const double eBe = ex * tx + ey * ty;
                 const double vxj = vj.x, vyj = vj.y;
                 const double dWVj = dW * Volj;
-                // viscous
-                const double coeff = eBe * ph.mu * dWVj / (r + 0.01 * h);
-                ax += coeff * (vxi - vxj);
-                ay += coeff * (vyi - vyj);
-                // transport
-                ix -= dWVj * tx;
-                iy -= dWVj * ty;
+                if (!later) {
+                    // viscous
+                    const double coeff = eBe * ph.mu * dWVj / (r + 0.01 * h);
+                    ax += coeff * (vxi - vxj);
+                    ay += coeff * (vyi - vyj);
+                    // transport
+                    ix -= dWVj * tx;
+                    iy -= dWVj * ty;
+                }
                 // pressure (Riemann-dissipated face pressure)
                 const double p_j = aj.y;
                 const double rho_bar = 0.5 * (rhoh_i + aj.z);
@@ -655,6 +673,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
                 py -= (p_face * ty) * dWVj;
             } else {
                 first_wall = min(first_wall, m);
+                if (later) continue;  // (wall entries contribute to the pressure part in the second loop only)
                 const double2 pj = w.pos[k];
                 const double4 wj = w.a[k];
                 const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
@@ -675,8 +694,8 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     ay = group_sum<LPP>(ay);
     ix = group_sum<LPP>(ix);
     iy = group_sum<LPP>(iy);
-    const double fpx = ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
-    const double fpy = ay * Voli;
+    const double fpx = later ? fp_own.x : ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
+    const double fpy = later ? fp_own.y : ay * Voli;
     if (active) {
         const double acx = fpx / mi, acy = fpy / mi;
         for (int m = first_wall; m < nn_all; ++m) {
@@ -700,9 +719,9 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         const double inv_m = 1.0 / mi;
         const double vxn = vxi + (fpx + fx) * inv_m * dt;
         const double vyn = vyi + (fpy + fy) * inv_m * dt;
-        double sx, sy;
-        transport_shift(ix, iy, h, ph.tc, sx, sy);
-        double xo = xi + sx, yo = yi + sy;
+        double sx = 0.0, sy = 0.0;
+        if (!later) transport_shift(ix, iy, h, ph.tc, sx, sy);
+        double xo = later ? p_now.x : xi + sx, yo = later ? p_now.y : yi + sy;
         xo += 0.5 * dt * vxi;
         yo += 0.5 * dt * vyi;
         xo += 0.5 * dt * vxn;
@@ -714,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         }
         t.posn[i] = make_double2(g.periodic ? wrap_x(xo, ph.DL) : xo, yo);  // a slab wraps when particles change owner
         t.veln[i] = make_double2(vxn, vyn);
-        t.fp[i] = make_double2(fpx, fpy);
+        if (!later) t.fp[i] = make_double2(fpx, fpy);
         t.f[i] = make_double2(fx, fy);
     }
     // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
@@ -1282,7 +1301,7 @@ __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phy
         if (!(c.drift <= half_skin)) c.need_rebuild = 1;
     }
     c.vmax = vmax;
-    c.t += c.dt;  // SPH_Poiseuille.m:267
+    c.t += c.n_in > 1 ? c.dt * c.n_in : c.dt;  // SPH_Poiseuille.m:267 (dual-rate: n_in sub-steps of dt were taken)
     c.dt_last = c.dt;
     c.step += 1;
     if (c.steps_left > 0) c.steps_left -= 1;
@@ -1356,7 +1375,7 @@ __device__ __forceinline__ void continuity_tail(Clock *clk, int q, const Phys &p
 template <int LPP, bool WALK, int TILE>
 __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                                 const FluidTmp &t, const Walls &w, int do_hist, int tail, int bid, int nb,
-                                                double2 *c_pos, double2 *c_vel, double *c_vol)
+                                                double2 *c_pos, double2 *c_vel, double *c_vol, int next_half = 0)
 {
     const int blk = xcd_block(bid, nb);
     const int tid = blk * kBlock + threadIdx.x;
@@ -1373,7 +1392,8 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const int e_row2 = (!WALK && LPP <= 8) ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
     const int e_row3 = (!WALK && LPP <= 8) ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     const bool lead = in_cap && sub == 0;
-    const double rhoh_i = lead ? t.a[i].z : 0.0;
+    const double4 a_own = lead ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
+    const double rhoh_i = a_own.z;
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
     const double dt = clk->dt;
     if (!clk->run[q]) return;
@@ -1454,6 +1474,11 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
         t.drhon[i] = drho_new;
         t.rho_out[i] = rho;
         t.p_out[i] = eos_pressure(rho, ph.rho0, ph.p0);
+        if (next_half) {  // dual-rate loop: another sub-step follows, with the density carried on (not re-summed)
+            double rhoh2, p2;
+            half_state(ph, rho, drho_new, dt, rhoh2, p2);
+            t.a[i] = make_double4(a_own.x, p2, rhoh2, rho);
+        }
         if (owns(g, xi, g.own_by_cell ? s.cell[i] : 0)) {
             v2 = vxi * vxi + vyi * vyi;
             if (v2 != v2) v2 = INFINITY;  // NaN poisons the max on purpose
@@ -1473,7 +1498,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     __shared__ double s_max[kBlock / 64];
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v2;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !next_half) {  // (an inner sub-step leaves the "ready" slots of the step's last pass E alone)
         double m = s_max[0];
         for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_max[k]);
         if (tail)
@@ -1486,7 +1511,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
 
 template <int LPP, bool WALK, int TILE>
 __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
-                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail)
+                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
@@ -1496,7 +1521,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
         continuity_tail(clk, q, ph, t, nb);
         return;
     }
-    continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol);
+    continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol, next_half);
 }
 
 // Small channels, steps that do not re-bin: pass E of this step and pass A of the NEXT step in one launch, side by

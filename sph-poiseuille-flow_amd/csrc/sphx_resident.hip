@@ -162,6 +162,8 @@ struct sphx_ctx {
     // (k_continuity_density).  The neighbour list and the {Vol, p, rho_h, rho} records then exist once per state parity:
     // tmp_par[p] is `tmp` with the buffers of parity p; out_par = the parity of the last executed step (its Vol).
     bool fuse_ea = false;
+    int n_in = 1;                // dual-rate loop: inner sub-steps per step slot (1 = the reference's single-rate loop)
+    DevBuf<double2> vel2;        // ... and the second velocity array its sub-steps alternate with
     DevBuf<double4> fa2;
     DevBuf<double> fvol2;
     DevBuf<int> nl_idx2, nl_cnt2;
@@ -256,13 +258,28 @@ ReorderArgs reorder_args(const double2 *pos, const double2 *vel, const double *d
     return ra;
 }
 
+// Inner sub-steps per step slot a context asking for the dual-rate loop would run (1 = single rate).
+int dual_rate_substeps(const sphx_params &prm)
+{
+    if (prm.dual_rate <= 1) return 1;
+    require(prm.dual_rate <= 4, "SPHX:Ctx:dual_rate", "dual_rate must be 0, 1 or 2..4 (inner sub-steps per outer step)");
+    const double h = prm.h;
+    const double dt_ac = 0.25 * h / (1.1 * prm.c_f);  // at max|v| = 0.1 c_f, where the reference's set-up runs
+    const double dt_visc = 0.125 * h * h * prm.rho0 / std::max(prm.mu, 1e-12);
+    const double dt_body = 0.25 * std::sqrt(h / std::max(std::fabs(prm.gravity_g), 1e-12));
+    const int fit = (int)std::floor(std::min(dt_visc, dt_body) / dt_ac);
+    return std::max(1, std::min(fit, (int)prm.dual_rate));
+}
+
 // The four neighbour passes on state view `s`, writing the end-of-step state through t.posn / veln / drhon.
 // only: 0 = all four, 1..4 = just density / kgc / forces / continuity (kernel timing)
 // dmode: 0 = pass A sweeps the cells; 1 = sweeps and writes the superset list (first step after a re-bin);
 //        2 = walks the superset list
 // tail: pass E gets one workgroup more, which advances the clock (no k_clock_scan after this step)
+// inner (dual-rate loop, compact kernels only): this launch of pass CD / E belongs to an inner sub-step -- CD does the
+//        pressure part only, E hands the next sub-step its half-step density
 template <int LPP>
-void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode, int tail)
+void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode, int tail, int inner)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
@@ -287,9 +304,9 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
     const char *name_e = tail ? "k_continuity_clock" : "k_continuity";
     if (!walk) {
         if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
-        if (!only || only == 3) launch(c, "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+        if (!only || only == 3) launch(c, inner ? "k_forces_inner" : "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, inner);
         if (!only || only == 4)
-            launch(c, name_e, k_continuity<LPP, false, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
+            launch(c, inner ? "k_continuity_inner" : name_e, k_continuity<LPP, false, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, inner);
     } else if constexpr (LPP <= 8) {
         // LDS tiles (tile_ranges): the force pass always; KGC and continuity where measured to pay (lds_tiles_be)
         constexpr int T = tile_slots(LPP);
@@ -302,22 +319,22 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             else launch(c, "k_forces", k_forces_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
         }
         if (!only || only == 4) {
-            if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
-            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail);
+            if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
+            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
         }
     }
 }
 
 void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0, int dmode = 0,
-                        int tail = 0)
+                        int tail = 0, int inner = 0)
 {
     switch (c->lpp) {
-        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode, tail); break;
-        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode, tail); break;
-        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode, tail); break;
-        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode, tail); break;
-        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode, tail); break;
-        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode, tail); break;
+        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
         default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
     }
 }
@@ -396,6 +413,23 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         if (dpart) dpart = c->vtile.get() + c->n_vtiles;
         n_red = c->n_vtiles;
     }
+    // Dual-rate loop: passes CD and E of the inner sub-steps 1 .. n_in-1 (CD of sub-step 0 comes first, E of the last
+    // sub-step after).  Sub-step m reads the velocities W_m and writes W_m+1; the W alternate between the step's output
+    // array and vel2 so that the last one lands in the output array.
+    auto inner_substeps = [c, q, &s](FluidTmp &t) {
+        if (c->n_in <= 1) { launch_physics_any(c, q, s, t, 0, 3); return; }
+        double2 *const w_final = t.veln;
+        auto w_of = [&](int m) { return ((c->n_in - m) & 1) ? c->vel2.get() : w_final; };  // W_m, m = 1 .. n_in
+        FluidSet sm = s;
+        t.veln = w_of(1);
+        launch_physics_any(c, q, sm, t, 0, 3);
+        for (int m = 1; m < c->n_in; ++m) {
+            launch_physics_any(c, q, sm, t, 0, 4, 0, 0, 1);  // E of sub-step m-1: rho, drho and the next half-step state
+            sm.vel = w_of(m);
+            t.veln = w_of(m + 1);
+            launch_physics_any(c, q, sm, t, 0, 3, 0, 0, 1);  // CD of sub-step m (pressure part)
+        }
+    };
     if (!rebuild && c->fuse_ea) {
         // pass A of this step ran inside the previous step's last launch, unless this is the first step on a fresh grid
         FluidTmp t = c->tmp_par[q], tn = c->tmp_par[1 - q];
@@ -403,7 +437,7 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
         if (pos == 0) launch_physics_any(c, q, s, t, 0, 1, 1);
         launch_physics_any(c, q, s, t, 0, 2);
-        launch_physics_any(c, q, s, t, 0, 3);
+        inner_substeps(t);
         launch_fused_ea(c, q, s, t, o, tn);
         return;
     }
@@ -423,10 +457,10 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         return;
     }
     if (c->fuse_ea) {  // re-binning step: pass A came with the previous step (or stands alone at pos 0), E has a launch of its own
-        const FluidTmp &t = c->tmp_par[q];
+        FluidTmp t = c->tmp_par[q];
         if (pos == 0) launch_physics_any(c, q, s, t, 1, 1, 1);
         launch_physics_any(c, q, s, t, 1, 2);
-        launch_physics_any(c, q, s, t, 1, 3);
+        inner_substeps(t);
         launch_physics_any(c, q, s, t, 1, 4);
     } else {
         launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
@@ -844,6 +878,11 @@ void ctx_alloc(sphx_ctx *c, int cap)
         c->tmp_par[1].a = c->fa2.get(); c->tmp_par[1].vol = c->fvol2.get();
         c->tmp_par[1].nl_idx = c->nl_idx2.get(); c->tmp_par[1].nl_cnt = c->nl_cnt2.get();
     }
+    // Opt-in dual-rate loop (sphx_params::dual_rate): small channels on the compact kernels, where the fused launches give
+    // the step a fixed shape.  The number of inner sub-steps is fixed per context (the graphs are static): how many acoustic
+    // steps fit into the viscous / body-force step, at most dual_rate.  Fine channels are viscous-limited: n_in = 1 there.
+    c->n_in = (c->fuse_ea && c->lpp >= 16) ? dual_rate_substeps(c->prm) : 1;
+    if (c->n_in > 1) { c->vel2.alloc(cap); c->vel2.zero(c->stream); }
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
@@ -913,6 +952,7 @@ void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
     k.drift = 0.0; k.need_rebuild = 0;
     k.fresh = 1; k.rebuild_now = 0; k.pos_count = 0; k.n_drift_rebuilds = 0;
     k.seq = 0;
+    k.n_in = c->n_in;
     if (!c->h_pub) SPHX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pub), sizeof(Clock), hipHostMallocMapped));
     void *pub_dev = nullptr;
     SPHX_HIP(hipHostGetDevicePointer(&pub_dev, c->h_pub, 0));
@@ -989,7 +1029,9 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // 79.5 / 72.1 / 72.6 / 74.8 at 130 k, 142 / 118 / 119 / 121 at 250 k (K = 5: its thin skin forces rebuilds + cool-downs) -> 8;
     // 0.5 M: 189 / 192 at K = 5 / 8, 6 M: 2 201 / 2 262 -> 5.
     int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 16 : (nf <= 300000 ? 8 : 5));
-    const double d_step = 0.035 * prm->h;
+    const int n_sub = (c->lpp >= 16 && !c->is_slab) ? dual_rate_substeps(*prm) : 1;  // dual-rate loop: a slot moves particles n_sub times as far
+    if (n_sub > 1 && prm->rebuild_every <= 0) K = std::max(2, K / n_sub);
+    const double d_step = 0.035 * prm->h * n_sub;
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
     if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
     c->rebuild_every = K;
@@ -1473,6 +1515,15 @@ SPHX_EXPORT int sphx_ctx_tuning(sphx_ctx *c, int *lanes_per_particle, int *steps
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     if (lanes_per_particle) *lanes_per_particle = c->lpp;
     if (steps_per_graph) *steps_per_graph = c->spg;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_ctx_substeps(sphx_ctx *c, int *n_inner)
+{
+    SPHX_TRY
+    require(c != nullptr && n_inner != nullptr, "SPHX:Ctx:null", "ctx / n_inner must not be NULL");
+    *n_inner = c->n_in;
     return SPHX_OK;
     SPHX_CATCH
 }

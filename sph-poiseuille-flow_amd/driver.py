@@ -43,6 +43,7 @@ class RunResult:
     tau_target: float = 0.0
     grid_policy: dict = field(default_factory=dict)  # resident engine: rebuild interval, skin, forced rebuilds
     full_profile_u: list = field(default_factory=list)  # whole-channel binned u_x(y) at every output point
+    n_inner: int = 1  # inner sub-steps per counted step (> 1 only with the opt-in dual-rate loop)
 
     def L2_time_mean(self, last=5):
         """L2 of the whole-channel profile averaged over the last `last` output points: the instantaneous profile of
@@ -72,15 +73,17 @@ def periodic_bounding(pos, n_fluid, DL):
 
 
 def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_particle=0, steps_per_graph=0,
-        rebuild_every=0, restart_path=None, postprocess_path=None):
+        rebuild_every=0, restart_path=None, postprocess_path=None, dual_rate=0):
     """Run to prm.t_end and return the final profile and L2 (SPH_Poiseuille.m:246-307 + postprocess :42).
 
     restart_path (resident engine): the reference's restart.mat protocol -- resume from it when
     prm.restart_from_file is set and its signature / sizes match (:132-163), rewrite it at every output point
-    (:295).  postprocess_path: write SPH_Poiseuille_postprocess.mat at the end (:305-306)."""
+    (:295).  postprocess_path: write SPH_Poiseuille_postprocess.mat at the end (:305-306).
+    dual_rate (resident engine, opt-in, NOT the reference's loop): up to that many acoustic sub-steps per outer step,
+    see sphx_params.dual_rate in include/sphx.h; the result then carries n_inner and steps counts outer steps."""
     parts = init_particles(prm) if parts is None else parts
     nf, nt = parts["n_fluid"], parts["n_total"]
-    t_start, step_start = 0.0, 0
+    t_start, step_start, n_inner = 0.0, 0, 1
     if restart_path and engine != "resident":
         raise ValueError("restart files are handled by the resident engine")
     if restart_path and prm.restart_from_file:
@@ -103,7 +106,8 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
     if engine == "resident":
         ctx = capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"],
                            parts["wall_vel"], t0=t_start, step0=step_start, lanes_per_particle=lanes_per_particle,
-                           steps_per_graph=steps_per_graph, rebuild_every=rebuild_every)
+                           steps_per_graph=steps_per_graph, rebuild_every=rebuild_every, dual_rate=dual_rate)
+        n_inner = ctx.substeps()
         t, step = t_start, step_start
         try:
             while t < prm.t_end - 1e-12:
@@ -183,4 +187,4 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
     return RunResult(prm=prm, n_fluid=nf, n_total=nt, t=t, steps=int(step), wall_seconds=wall, pos=pos, vel=vel,
                      y_mid=y_mid, u_mean=u_mean, u_exact=u_exact, L2_error=l2_error(u_mean, u_exact),
                      profile_times=profile_times, mid_profile_u=mid_profiles, tau_bottom=tau_b, tau_top=tau_t,
-                     tau_target=prm.gravity_g * prm.rho0 * prm.DH / 2, grid_policy=policy, full_profile_u=full_profiles)
+                     tau_target=prm.gravity_g * prm.rho0 * prm.DH / 2, grid_policy=policy, full_profile_u=full_profiles, n_inner=n_inner)

@@ -38,6 +38,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         p.mu = fld(cfg, "mu"); p.c_f = fld(cfg, "c_f"); p.p0 = fld(cfg, "p0"); p.inv_sigma0 = fld(cfg, "inv_sigma0");
         p.gravity_g = fld(cfg, "gravity_g"); p.transport_coeff = fld(cfg, "transport_coeff"); p.t_end = fld(cfg, "t_end");
         p.sort_interval = (int32_t)fld(cfg, "sort_interval");
+        if (mxGetField(cfg, 0, "dual_rate")) p.dual_rate = (int32_t)fld(cfg, "dual_rate");  /* optional, see sphx.h */
         ok(sphx_ctx_create(&c, &p, (int)mxGetScalar(prhs[2]), (int)mxGetScalar(prhs[3]), mxGetDoubles(prhs[4]),
                            mxGetDoubles(prhs[5]), mxGetDoubles(prhs[6]), mxGetDoubles(prhs[7]), mxGetDoubles(prhs[8]),
                            mxGetScalar(prhs[9]), (int64_t)mxGetScalar(prhs[10])));

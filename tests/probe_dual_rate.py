@@ -1,0 +1,15 @@
+"""Probe: the opt-in dual-rate loop on coarse channels (run on the GPU box): steps, wall time, L2, tau vs single rate."""
+import importlib, sys, time
+sys.path.insert(0, ".")
+pkg = importlib.import_module("sph-poiseuille-flow_amd")
+cfgmod = importlib.import_module("sph-poiseuille-flow_amd.config")
+driver = importlib.import_module("sph-poiseuille-flow_amd.driver")
+
+for dp, DL, t_end in ((0.05, 1.2, 20.0), (0.025, 2.0, 20.0), (0.02, 4.0, 5.0)):
+    for dr in (0, 2, 4, 8):
+        prm = cfgmod.params_from_values(dp=dp, DL=DL, end_time=t_end, output_interval=1.0)
+        r = driver.run(prm, dual_rate=dr)
+        print(f"dp={dp} DL={DL} dual_rate={dr} n_inner={r.n_inner} steps={r.steps} wall={r.wall_seconds:.3f}s "
+              f"L2={100*r.L2_error:.3f}% L2mean={100*r.L2_time_mean():.3f}% tau={r.tau_bottom:.5f}/{r.tau_top:.5f} "
+              f"target={r.tau_target:.5f} K={r.grid_policy.get('rebuild_every')} forced={r.grid_policy.get('forced_rebuilds')}",
+              flush=True)

@@ -1,0 +1,80 @@
+"""-m gpu: the opt-in dual-rate loop (sphx_params.dual_rate).  It is NOT the reference's
+loop (SPH_Poiseuille.m:250-292 takes one acoustic step per density summation), so there is no oracle for it: the
+checks are that asking for it changes nothing unless it is eligible, that the default path is untouched, and that
+the physics it produces matches the single-rate run against the analytic profile (SPH_Poiseuille_postprocess.m:67-80)
+and the wall-shear target g*rho0*DH/2."""
+import numpy as np
+import pytest
+
+from helpers import make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(capi, prm, parts, **kw):
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    return capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
+                        t_end=1e9, **kw)
+
+
+def test_dual_rate_off_is_the_default_path(cfgmod, geom, capi):
+    prm, parts = make_case(cfgmod, geom, dp=0.025, DL=2.0, jitter=0.1, seed=3, developed=True)
+    outs = []
+    for dr in (0, 1):
+        with _ctx(capi, prm, parts, dual_rate=dr) as ctx:
+            assert ctx.substeps() == 1
+            st = ctx.advance(1e9, max_steps=40)
+            outs.append((st, ctx.download()))
+    assert outs[0][0] == outs[1][0]
+    for k, v in outs[0][1].items():
+        assert np.array_equal(v, outs[1][1][k]), k
+
+
+def test_dual_rate_needs_an_eligible_context(cfgmod, geom, capi):
+    # viscous-limited (fine) channel: no acoustic sub-step fits, and large channels run other kernels
+    prm, parts = make_case(cfgmod, geom, dp=0.005, DL=0.5, jitter=0.0, seed=1, developed=False)
+    with _ctx(capi, prm, parts, dual_rate=4) as ctx:
+        assert ctx.substeps() == 1
+    prm, parts = make_case(cfgmod, geom, dp=0.025, DL=2.0, jitter=0.0, seed=1, developed=False)
+    with _ctx(capi, prm, parts, dual_rate=2, lanes_per_particle=8) as ctx:
+        assert ctx.substeps() == 1
+    with pytest.raises(capi.SphxError):
+        _ctx(capi, prm, parts, dual_rate=9)
+
+
+def test_dual_rate_outer_step_advances_time_by_all_substeps(cfgmod, geom, capi):
+    prm, parts = make_case(cfgmod, geom, dp=0.025, DL=2.0, jitter=0.05, seed=2, developed=True)
+    with _ctx(capi, prm, parts, dual_rate=2) as ctx:
+        assert ctx.substeps() == 2
+        st1 = ctx.advance(1e9, max_steps=1)
+        assert st1["step"] == 1 and abs(st1["t"] - 2 * st1["dt_last"]) <= 1e-15
+        st = ctx.advance(1e9, max_steps=60)  # crosses re-binning steps (K = 8)
+        got = ctx.download()
+        assert st["step"] == 61 and ctx.grid_policy()["rebuild_every"] < 60
+    with _ctx(capi, prm, parts) as ctx:
+        ref_st = ctx.advance(st["t"])
+        ref = ctx.download()
+    # same simulated time by both loops from the same start: the fields agree to the time-integration error
+    nf = parts["n_fluid"]
+    assert abs(ref_st["t"] - st["t"]) <= 1e-9
+    assert abs(ref_st["step"] - 2 * st["step"]) <= 3
+    # (the jittered start rings with acoustic waves, which the two loops integrate differently: RMS 1 %, worst particle 5 %)
+    vscale = np.max(np.abs(ref["vel"][:nf]))
+    dv = got["vel"][:nf] - ref["vel"][:nf]
+    assert np.sqrt(np.mean(dv * dv)) <= 0.01 * vscale and np.max(np.abs(dv)) <= 0.05 * vscale
+    assert np.max(np.abs(got["rho"][:nf] - ref["rho"][:nf])) <= 5e-3 * prm.rho0
+
+
+def test_dual_rate_run_matches_single_rate_physics(cfgmod, driver):
+    res = {}
+    for dr in (0, 2):
+        prm = cfgmod.params_from_values(dp=0.025, DL=2.0, end_time=20.0, output_interval=1.0)
+        res[dr] = driver.run(prm, dual_rate=dr)
+    one, two = res[0], res[2]
+    assert one.n_inner == 1 and two.n_inner == 2
+    assert abs(two.steps * 2 - one.steps) <= 0.02 * one.steps
+    assert two.L2_time_mean() <= one.L2_time_mean() + 0.003  # within 0.3 percentage points of the single-rate loop
+    assert two.L2_time_mean() <= 0.012
+    for tau in (two.tau_bottom, two.tau_top):
+        assert abs(tau - two.tau_target) <= 0.03 * two.tau_target
+    assert two.grid_policy["forced_rebuilds"] == 0
