@@ -9,11 +9,15 @@ OUT="$ROOT/gpurun_out/pmc_${TAG}_${WL}"
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --workload $WL --lpp $LPP --steps $STEPS --warmup 4 --no-cpu-baseline --no-aux --profile-steps 0 $EXTRA"
 i=0
-for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM" \
+# PMC_GROUPS="A B C;D E" overrides the counter groups (one rocprofv3 run per ';'-separated group)
+if [ -n "$PMC_GROUPS" ]; then IFS=';' read -r -a GROUPS_ <<< "$PMC_GROUPS"; else GROUPS_=(); fi
+for grp in "${GROUPS_[@]:-}" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" \
            "TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
            "FETCH_SIZE" "WRITE_SIZE"; do
+  [ -z "$grp" ] && continue
+  [ -n "$PMC_GROUPS" ] && [ $i -ge ${#GROUPS_[@]} ] && break
   i=$((i+1))
   timeout -k 10 280 rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -- $CMD > "$OUT/g$i.json" 2> "$OUT/g$i.err" || echo "group $i failed"
 done
