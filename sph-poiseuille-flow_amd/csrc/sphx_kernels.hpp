@@ -960,6 +960,192 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     }
 }
 
+// pass A, sweeping the cells (see density_body MODE 0 / 1), large-channel form.  At a few lanes per particle a lane tests
+// 20-40 candidates: in the compact form every trip was a load followed by a wait for it.  Here the candidates' addresses
+// -- three contiguous index ranges, known before the loop -- are requested two trips ahead, the minimum-image fold runs
+// only in wavefronts near the periodic seam, the kernel value is branch-free, and kernel value and list stores are spent on
+// the candidates inside the radius only (two phases, see fluid_sweep).
+template <int LPP, int MODE>
+__device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
+                                                     const FluidTmp &t, const Walls &w, int bid, int nblk, bool half)
+{
+    static_assert(MODE == 0 || MODE == 1, "sweeping forms only");
+    SPHX_PASS_INDEX_AT(bid, nblk);
+    const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
+    const int ci = in_cap ? s.cell[i] : 0;
+    const bool lead = in_cap && sub == 0;
+    const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
+    const double dt = clk->dt;
+    if (!clk->run[q]) return;
+    const bool active = i < clk->n;
+    constexpr bool record = MODE == 1;
+    double s_in = 0.0, s_ct = 0.0;
+    int cnt = 0, scnt = 0;
+    const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
+    const int row_base = tid - sub;
+    const int half_shift = gbase & 31;
+    const unsigned grp_mask = LPP >= 32 ? 0xffffffffu : ((1u << (LPP & 31)) - 1u);
+    const unsigned below_me = (1u << sub) - 1u;
+    auto group_bits = [&](bool acc) -> unsigned {
+        const unsigned long long bal = __ballot(acc);
+        const unsigned half_ = lane < 32 ? (unsigned)bal : (unsigned)(bal >> 32);
+        return (half_ >> half_shift) & grp_mask;
+    };
+    auto push_to = [&](int *idx, int cap, int &n, bool acc, int entry) {
+        const unsigned grp = LPP == 1 ? (acc ? 1u : 0u) : group_bits(acc);
+        if (acc) {
+            const int m = n + __popc(grp & below_me);
+            if (m / LPP < cap) idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+        }
+        n += __popc(grp);
+    };
+    const double xi = pi.x, yi = pi.y;
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
+    bool near_wall = false;
+    if (active) {
+        const int cx = ci / g.ncy, cy = ci - cx * g.ncy;
+        const int cylo = max(cy - 1, 0), cyhi = min(cy + 1, g.ncy - 1);
+        near_wall = w.row_any[cy] != 0;
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox) {
+            int col = cx + ox;
+            bool ok = true;
+            if (g.periodic) {
+                if (duplicate_column(g, ox)) ok = false;
+                if (col < 0) col += g.ncx;
+                else if (col >= g.ncx) col -= g.ncx;
+            } else if (col < 0 || col >= g.ncx) {
+                ok = false;
+            }
+            const int c0 = col * g.ncy + cylo, c1 = col * g.ncy + cyhi + 1;
+            lo[ox + 1] = ok ? s.start[c0] : 0;
+            hi[ox + 1] = ok ? s.start[c1] : 0;
+            wlo[ox + 1] = ok ? w.start[c0] : 0;
+            whi[ox + 1] = ok ? w.start[c1] : 0;
+        }
+    }
+    // the three ranges as ONE virtual index range (see density_body); a group's lanes take LPP consecutive candidates per trip
+    const int n0 = hi[0] - lo[0], n1 = hi[1] - lo[1], n2 = hi[2] - lo[2];
+    const int nfl = n0 + n1 + n2;
+    // v -> particle index: two independent selects (a nested choice of three becomes branches, or a table in scratch memory)
+    const int n01 = n0 + n1, off2 = lo[2] - n01, d12 = (lo[1] - n0) - off2, d01 = lo[0] - (lo[1] - n0);
+    auto fluid_index = [&](int v) { return v + off2 + (v < n01 ? d12 : 0) + (v < n0 ? d01 : 0); };
+    // Two phases per chunk of 64 trips.  Only a third of the candidates of the 3 x 3 cells lie inside the (superset) radius,
+    // and kernel value + packed list stores are four fifths of a trip's instructions: phase 1 only measures distances and
+    // marks the trips inside the radius in a bit mask (positions requested three trips ahead, each into a register of its
+    // own -- a rotating buffer would make every turn wait for the newest request; requests past the end repeat the last
+    // candidate: no branch around the load); phase 2 visits the marked trips only.  A group's lanes mark different
+    // trips, so its list holds the same entries as the compact form's in a slightly different (still fixed) order.
+    const double r2_mark = record ? t.sl_rcut2 : ph.kc.rcut2;
+    auto fluid_sweep = [&](auto fold) {
+        if (nfl <= 0) return;
+        auto index_at = [&](int v) { return fluid_index(min(v, nfl - 1)); };
+        auto dist2 = [&](const double2 &pj) {
+            double dx = xi - pj.x;
+            if (decltype(fold)::value) dx = min_image(g, dx);
+            const double dy = yi - pj.y;
+            return dx * dx + dy * dy;
+        };
+        for (int base = 0; base < nfl; base += 64 * LPP) {
+            const int n_tr = min((nfl - base + LPP - 1) / LPP, 64);  // trips of this chunk (the same for the group's lanes)
+            unsigned long long mask = 0;
+            auto mark = [&](int tt, const double2 &pj) {
+                const double r2 = dist2(pj);
+                const bool inside = base + tt * LPP + sub < nfl && r2 > kR2Min && r2 < r2_mark;
+                mask |= (unsigned long long)(inside ? 1 : 0) << tt;
+            };
+            double2 pa = s.pos[index_at(base + sub)], pb = s.pos[index_at(base + LPP + sub)],
+                    pc = s.pos[index_at(base + 2 * LPP + sub)];
+            for (int tt = 0; tt < n_tr; tt += 3) {
+                mark(tt, pa);
+                pa = s.pos[index_at(base + (tt + 3) * LPP + sub)];
+                if (tt + 1 < n_tr) mark(tt + 1, pb);
+                pb = s.pos[index_at(base + (tt + 4) * LPP + sub)];
+                if (tt + 2 < n_tr) mark(tt + 2, pc);
+                pc = s.pos[index_at(base + (tt + 5) * LPP + sub)];
+            }
+            int rounds = __popcll(mask);
+#pragma unroll
+            for (int off = LPP / 2; off > 0; off >>= 1) rounds = max(rounds, __shfl_xor(rounds, off));
+            // (the position of the next marked trip is requested before the current one is worked on)
+            auto next_marked = [&](bool &has, int &k) {
+                has = mask != 0;
+                const int tt = has ? __ffsll((long long)mask) - 1 : 0;
+                mask &= mask - 1;
+                k = index_at(base + tt * LPP + sub);
+            };
+            bool has, has_n;
+            int k, k_n;
+            next_marked(has, k);
+            double2 pj = s.pos[k];
+            for (int r = 0; r < rounds; ++r) {
+                next_marked(has_n, k_n);
+                const double2 pj_n = s.pos[k_n];
+                const double r2 = dist2(pj);
+                const bool acc = has && r2 < ph.kc.rcut2;
+                const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
+                s_in += acc ? W : 0.0;
+                push_to(t.nl_idx, t.nl_cap, cnt, acc, k);
+                if (record) push_to(t.sl_idx, t.sl_cap, scnt, has, k);
+                has = has_n; k = k_n; pj = pj_n;
+            }
+        }
+    };
+    if (__any(active && near_seam(g, xi))) fluid_sweep(std::true_type{});
+    else fluid_sweep(std::false_type{});
+    int cnt_fl = cnt, scnt_fl = scnt;
+    if (near_wall) {
+        const int w0 = whi[0] - wlo[0], w1 = whi[1] - wlo[1], w2 = whi[2] - wlo[2];
+        const int nwl = w0 + w1 + w2;
+        auto wall_index = [&](int v) { return v < w0 ? wlo[0] + v : (v < w0 + w1 ? wlo[1] + (v - w0) : wlo[2] + (v - w0 - w1)); };
+        if (nwl > 0) {
+            int ka = wall_index(min(sub, nwl - 1));
+            double2 pa = w.pos[ka];
+            double va = w.a[ka].x;
+            for (int vb = 0; vb < nwl; vb += LPP) {
+                const int kb = wall_index(min(vb + LPP + sub, nwl - 1));
+                const double2 pb = w.pos[kb];
+                const double vb_ = w.a[kb].x;
+                const double dx = min_image(g, xi - pa.x), dy = yi - pa.y;
+                const double r2 = dx * dx + dy * dy;
+                const bool in = vb + sub < nwl && r2 > kR2Min;
+                const bool acc = in && r2 < ph.kc.rcut2;
+                const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
+                s_ct += acc ? W * va : 0.0;
+                push_to(t.nl_idx, t.nl_cap, cnt, acc, ka | kWallBit);
+                if (record) push_to(t.sl_idx, t.sl_cap, scnt, in && r2 < t.sl_rcut2, ka | kWallBit);
+                ka = kb; pa = pb; va = vb_;
+            }
+        }
+    }
+    if (active && cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
+    cnt_fl = min(cnt_fl, cnt);
+    if (record && active && scnt > t.sl_cap * LPP) { atomicOr(t.flags, 1); scnt = t.sl_cap * LPP; }
+    scnt_fl = min(scnt_fl, scnt);
+    if (tid < t.nl_stride)
+        t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
+    if (record && tid < t.nl_stride)
+        t.sl_cnt[tid] = (scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0) | ((scnt_fl > sub ? (scnt_fl - sub + LPP - 1) / LPP : 0) << 16);
+    s_in = group_sum<LPP>(s_in);
+    s_ct = group_sum<LPP>(s_ct);
+    if (active && sub == 0) {
+        const double rho = density_from_sigma(ph.w0 + s_in, s_ct, mass_i, ph.rho0, ph.inv_sigma0);
+        double rhoh = rho + 0.5 * dt * drho_i;
+        if (rhoh < 1e-10) rhoh = ph.rho0;
+        t.a[i] = half ? make_double4(mass_i / rho, eos_pressure(rhoh, ph.rho0, ph.p0), rhoh, rho)
+                      : make_double4(mass_i / rho, 0.0, 0.0, rho);
+        t.vol[i] = mass_i / rho;
+    }
+}
+
+template <int LPP, int MODE>
+__global__ __launch_bounds__(kBlock) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+                                                            FluidTmp t, Walls w, int cond_fresh)
+{
+    if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
+    density_sweep_body_w<LPP, MODE>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true);
+}
+
 template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                       FluidTmp t, Walls w, int cond_fresh)

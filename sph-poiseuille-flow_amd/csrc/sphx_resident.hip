@@ -162,6 +162,7 @@ struct sphx_ctx {
     // (k_continuity_density).  The neighbour list and the {Vol, p, rho_h, rho} records then exist once per state parity:
     // tmp_par[p] is `tmp` with the buffers of parity p; out_par = the parity of the last executed step (its Vol).
     bool fuse_ea = false;
+    bool sweep_kernels = false;  // pass A's cell sweep in its large-channel form (k_density_sweep_w)
     int n_in = 1;                // dual-rate loop: inner sub-steps per step slot (1 = the reference's single-rate loop)
     DevBuf<double2> vel2;        // ... and the second velocity array its sub-steps alternate with
     DevBuf<double4> fa2;
@@ -284,15 +285,21 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
     if (!only || only == 1) {
-        if (dmode == 0) launch(c, "k_density", k_density<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
-        else if (dmode == 1) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
+        bool walk_w = false, sweep_w = false;  // large channels (few lanes per particle): the "_w" forms, see sphx_kernels.hpp
+        if constexpr (LPP <= 8) { walk_w = c->walk_kernels; sweep_w = c->sweep_kernels; }
+        // the cell sweep: mode 0 writes the step's list, mode 1 the superset list as well
+        auto sweep = [&](const char *name, auto mode, int cond) {
+            constexpr int M = decltype(mode)::value;
+            if (!sweep_w) launch(c, name, k_density<LPP, M>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+            else if constexpr (LPP <= 8) launch(c, name, k_density_sweep_w<LPP, M>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+        };
+        if (dmode == 0) sweep("k_density", std::integral_constant<int, 0>{}, -1);
+        else if (dmode == 1) sweep("k_density_build", std::integral_constant<int, 1>{}, -1);
         else {
             // dmode 2: walk the superset list; 3 (dynamic contexts): build and walk, each skipping itself according to the
             // clock's `fresh`
             const int cond = dmode == 2 ? -1 : 0;
-            if (dmode == 3) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, 1);
-            bool walk_w = false;
-            if constexpr (LPP <= 8) walk_w = c->walk_kernels;
+            if (dmode == 3) sweep("k_density_build", std::integral_constant<int, 1>{}, 1);
             if (!walk_w) launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
             else if constexpr (LPP <= 8) launch(c, "k_density_walk", k_density_w<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
         }
@@ -1008,6 +1015,7 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
     check_lpp(c->lpp);
     c->walk_kernels = c->lpp <= 8 && !std::getenv("SPHX_NO_WALK_KERNELS");  // (the environment switches are for A/B runs)
+    c->sweep_kernels = c->walk_kernels && !std::getenv("SPHX_NO_SWEEP_KERNELS");
     c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");
     c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && c->nf >= 2000000;
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 40;  // measured at C2: 10 -> 25.4, 40 -> 25.1, 80 -> 24.8 us/step
@@ -1633,6 +1641,7 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(n_local);
     check_lpp(c->lpp);
     c->walk_kernels = c->lpp <= 8 && !std::getenv("SPHX_NO_WALK_KERNELS");  // (the environment switches are for A/B runs)
+    c->sweep_kernels = c->walk_kernels && !std::getenv("SPHX_NO_SWEEP_KERNELS");
     c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");
     c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_local >= 2000000;
     c->spg = 2;
