@@ -148,13 +148,14 @@ def test_two_column_channel_matches_oracle(cfgmod, geom, mex, capi, oracle, DL):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert_close(a[4], b[4], rtol=1e-13, atol=1e-15 * prm.DL, name="r")
     ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=4, enable_sort=False)
-    with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
-                      t_end=1e9) as ctx:
-        assert ctx.info()["n_cell_x"] == 2 and ctx.grid_policy()["rebuild_every"] == 1
-        ctx.advance(1e9, max_steps=4)
-        got = ctx.download()
-    for k in ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B"):
-        assert_close(got[k], ref[k], rtol=1e-9, atol_scale=1e-10, name=k)
+    for lpp in (0, 4, 2):  # automatic (compact kernels) and the large-channel kernel forms (cell sweep with the duplicate column)
+        with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
+                          t_end=1e9, lanes_per_particle=lpp) as ctx:
+            assert ctx.info()["n_cell_x"] == 2 and ctx.grid_policy()["rebuild_every"] == 1
+            ctx.advance(1e9, max_steps=4)
+            got = ctx.download()
+        for k in ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B"):
+            assert_close(got[k], ref[k], rtol=1e-9, atol_scale=1e-10, name=f"{k}/lpp={lpp}")
 
 
 @pytest.mark.parametrize("n_cols_dp", [4, 2])
