@@ -904,12 +904,14 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     const int rows_fl = LPP == 1 ? my_fl : __shfl(my_fl, gbase + LPP - 1);
     const double xi = pi.x, yi = pi.y;
     double s_in = 0.0, s_ct = 0.0;
-    int ea = e_row0, eb = e_row1;
-    int ec = rows_fl > 2 ? t.sl_idx[2 * (size_t)t.nl_stride + tid] : 0;
+    // Three rows per turn.  A row is entry -> position -> test: the entries run six rows ahead (two turns), the positions three
+    // (each requested into the register whose value has just been used -- a rotating buffer would make every turn wait for
+    // the newest request); requests past the last row repeat it: no branch around the loads, the values are not used.
     auto fluid_rows = [&](auto fold) {
-        for (int m = 0; m < rows_fl; ++m) {
-            const int ed = m + 3 < rows_fl ? t.sl_idx[(size_t)(m + 3) * t.nl_stride + tid] : 0;
-            const double2 pj = s.pos[ea];
+        if (rows_fl <= 0) return;
+        const int last = rows_fl - 1;
+        auto entry = [&](int m) { return t.sl_idx[(size_t)min(m, last) * t.nl_stride + tid]; };
+        auto row = [&](int e, const double2 &pj) {
             double dx = xi - pj.x;
             if (decltype(fold)::value) dx = min_image(g, dx);
             const double dy = yi - pj.y;
@@ -917,8 +919,21 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
             const bool acc = r2 > kR2Min && r2 < ph.kc.rcut2;
             const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));  // (NaN for a coincident pair: discarded by the select)
             s_in += acc ? W : 0.0;
-            push(acc, ea);
-            ea = eb; eb = ec; ec = ed;
+            push(acc, e);
+        };
+        int ea = e_row0, eb = rows_fl > 1 ? e_row1 : e_row0, ec = entry(2);
+        int ed = entry(3), ee = entry(4), ef = entry(5);
+        double2 pa = s.pos[ea], pb = s.pos[eb], pc = s.pos[ec];
+        for (int m = 0; m < rows_fl; m += 3) {
+            const int eg = entry(m + 6), eh = entry(m + 7), ei = entry(m + 8);
+            row(ea, pa);
+            pa = s.pos[ed];
+            if (m + 1 < rows_fl) row(eb, pb);
+            pb = s.pos[ee];
+            if (m + 2 < rows_fl) row(ec, pc);
+            pc = s.pos[ef];
+            ea = ed; eb = ee; ec = ef;
+            ed = eg; ee = eh; ef = ei;
         }
     };
     if (__any(active && near_seam(g, xi))) fluid_rows(std::true_type{});
