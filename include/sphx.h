@@ -286,6 +286,9 @@ int sphx_slab_finish(sphx_ctx *ctx, const double *recv_left_dev, const double *r
  * copies as the transport (tests and rehearsals on a one-GPU box).  Both return without waiting; sphx_slab_sync
  * waits and reports. */
 int sphx_comm_unique_id(void *id_bytes, int capacity);
+/* Diagnostic: runs the exchange pattern of sphx_slab_run (grouped sends / receives, the all-reduce) on a one-rank
+ * communicator on the current device and checks what comes back.  SPHX_OK, or an error naming the RCCL call that failed. */
+int sphx_comm_selftest(void);
 int sphx_slab_comm_init(sphx_ctx *ctx, const void *id_bytes);
 int sphx_slab_comm_destroy(sphx_ctx *ctx);
 int sphx_slab_run(sphx_ctx *ctx, double t_target, int64_t n_steps);

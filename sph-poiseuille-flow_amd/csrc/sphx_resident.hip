@@ -1971,6 +1971,64 @@ SPHX_EXPORT int sphx_slab_comm_init(sphx_ctx *c, const void *id_bytes)
     SPHX_CATCH
 }
 
+// The exchange pattern of sphx_slab_run on a communicator of ONE rank (its own neighbour on both sides): two sends and two
+// receives in one group -- the receives must be served in the order of the sends, which is what the two-rank ring relies
+// on -- then the 16-byte all-reduce(max).  Checks the dlopen'ed entry points, enum values and stream use on this machine.
+SPHX_EXPORT int sphx_comm_selftest(void)
+{
+    SPHX_TRY
+    ensure_device();
+    Rccl &R = Rccl::get();
+    ncclUniqueId id;
+    R.check(R.GetUniqueId(&id), "ncclGetUniqueId");
+    ncclComm_t comm = nullptr;
+    R.check(R.CommInitRank(&comm, 1, id, 0), "ncclCommInitRank");
+    hipStream_t st = nullptr;
+    const size_t n = 1000;
+    DevBuf<double> sl(n), sr(n), rl(n), rr(n), v(2), vg(2);
+    DevBuf<int> il(n), ir(n), jl(n), jr(n);
+    std::vector<double> hl(n), hr(n), got_l(n), got_r(n);
+    std::vector<int> kl(n), kr(n), gi_l(n), gi_r(n);
+    for (size_t k = 0; k < n; ++k) { hl[k] = 1.0 + k; hr[k] = -2.0 - k; kl[k] = 7 + (int)k; kr[k] = -9 - (int)k; }
+    const double hv[2] = {3.25, -1.5};
+    double gv[2] = {0.0, 0.0};
+    bool ok = false;
+    try {
+        SPHX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        sl.upload(hl.data(), n, st); sr.upload(hr.data(), n, st); il.upload(kl.data(), n, st); ir.upload(kr.data(), n, st);
+        v.upload(hv, 2, st);
+        rl.zero(st); rr.zero(st); jl.zero(st); jr.zero(st); vg.zero(st);
+        auto ring = [&](const void *to_l, const void *to_r, void *from_l, void *from_r, ncclDataType_t ty) {
+            R.check(R.GroupStart(), "ncclGroupStart");
+            R.check(R.Send(to_l, n, ty, 0, comm, st), "ncclSend");
+            R.check(R.Send(to_r, n, ty, 0, comm, st), "ncclSend");
+            R.check(R.Recv(from_r, n, ty, 0, comm, st), "ncclRecv");
+            R.check(R.Recv(from_l, n, ty, 0, comm, st), "ncclRecv");
+            R.check(R.GroupEnd(), "ncclGroupEnd");
+        };
+        ring(sl.get(), sr.get(), rl.get(), rr.get(), ncclDouble);
+        ring(il.get(), ir.get(), jl.get(), jr.get(), ncclInt32);
+        R.check(R.AllReduce(v.get(), vg.get(), 2, ncclDouble, ncclMax, comm, st), "ncclAllReduce");
+        SPHX_HIP(hipMemcpyAsync(got_l.data(), rl.get(), n * sizeof(double), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipMemcpyAsync(got_r.data(), rr.get(), n * sizeof(double), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipMemcpyAsync(gi_l.data(), jl.get(), n * sizeof(int), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipMemcpyAsync(gi_r.data(), jr.get(), n * sizeof(int), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipMemcpyAsync(gv, vg.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipStreamSynchronize(st));
+        // what went to the left arrives "from the right" and vice versa
+        ok = got_r == hl && got_l == hr && gi_r == kl && gi_l == kr && gv[0] == hv[0] && gv[1] == hv[1];
+    } catch (...) {
+        (void)R.CommDestroy(comm);
+        if (st) (void)hipStreamDestroy(st);
+        throw;
+    }
+    R.check(R.CommDestroy(comm), "ncclCommDestroy");
+    SPHX_HIP(hipStreamDestroy(st));
+    if (!ok) throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", "RCCL self-test: the exchanged data came back wrong");
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
 SPHX_EXPORT int sphx_slab_comm_destroy(sphx_ctx *c)
 {
     SPHX_TRY

@@ -106,3 +106,16 @@ def test_slab_native_ring_in_one_process(world, dp, DL, steps, kw):
     assert_close(pos, ref["pos"][:nf], name="pos", **tol)
     assert_close(vel, ref["vel"][:nf], name="vel", **tol)
     assert_close(drho, ref["drho_dt"][:nf], name="drho_dt", **tol)
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_pattern_on_one_rank():
+    """No second GPU on the test box (RCCL refuses two ranks on one device): the next best check of sphx_slab_run's RCCL
+    calls is the library's self-test -- the dlopen'ed entry points, the enum values, the grouped two sends / two receives
+    to the same peer (served in order, which the two-rank ring relies on) and the 16-byte all-reduce(max), on a
+    communicator of one rank."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module("sph-poiseuille-flow_amd")
+    pkg.capi.check(pkg.capi.lib().sphx_comm_selftest())
+    pkg.capi.check(pkg.capi.lib().sphx_comm_selftest())  # (communicators come and go cleanly)
