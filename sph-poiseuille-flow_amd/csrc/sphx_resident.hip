@@ -787,8 +787,11 @@ int pick_lpp(int nf)
     // balanced neighbour list 4 lanes beat 1-2 even at 6 M particles, 32 beat 16 at 5 k)
     // Round 2 (entries ahead, LDS tile in the force pass): 2 lanes beat 4 from 0.5 M particles (189 vs 193 us/step) and
     // clearly at 6 M (2195 vs 2416); at 65 k particles 4 lanes keep more waves in flight (51 vs 60 us/step).
+    // With pass E and the next pass A in one launch and the clock in its tail (up to 2048 workgroups: 131 k particles at
+    // 4 lanes, 262 k at 2) the three-launch step of 2 lanes beats the five launches of 4: 194 k particles 90.9 vs 96.4 us/step,
+    // 259 k 109.1 vs 117.4; at 130 k, where both fuse, 4 lanes win (68.0 vs 70.6).
     const long target = 256L * 4 * 4 * 64;
-    if (nf >= 250000) return 2;
+    if (nf > 131072) return 2;
     int lpp = 4;
     while (lpp < 32 && (long)nf * lpp * 2 <= target) lpp *= 2;
     return lpp;
@@ -1016,7 +1019,8 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     check_lpp(c->lpp);
     c->walk_kernels = c->lpp <= 8 && !std::getenv("SPHX_NO_WALK_KERNELS");  // (the environment switches are for A/B runs)
     c->sweep_kernels = c->walk_kernels && !std::getenv("SPHX_NO_SWEEP_KERNELS");
-    c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");
+    c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");  // (65 k particles: 46.8 with, 46.3 us/step without;
+    // 100-130 k: equal; 194 k: 96.4 / 97.1; 259 k: 117.3 / 119.5; 360 k: 145.8 / 151.0 -- kept on at every size)
     c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && c->nf >= 2000000;
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 40;  // measured at C2: 10 -> 25.4, 40 -> 25.1, 80 -> 24.8 us/step
     if (c->spg & 1) c->spg += 1;

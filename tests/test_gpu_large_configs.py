@@ -1,4 +1,4 @@
-"""-m gpu: BASELINE.json configs[2..4] (C3 dp 0.01/DL 6, C4 dp 0.005/DL 12, C5 dp 0.002/DL 24) on the DEFAULT
+"""-m gpu: BASELINE.json configs[2..4] (C3 dp 0.01/DL 6, C4 dp 0.005/DL 12, C5 dp 0.002/DL 24) and one size in between on the DEFAULT
 context against the oracle's time loop -- the code paths the small cases never reach: automatic lanes per
 particle (4 / 2 / 2) with the large-channel kernels (entries ahead, fluid / wall loops, LDS tiles), the multi-block cell scan (> 8 192 cells: k_scan_tiles / k_scan_add), k_max_tiles (> 16 k
 workgroups), the grid-stride re-binning kernels, size_t index products and, from 10^6 fluid particles, the
@@ -20,6 +20,8 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
 #        name   dp     DL    steps  expected policy
 CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False)),
+         # 194 k particles: the largest channels whose step is three launches (2 lanes per particle, clock in the tail of E||A)
+         ("M194k", 0.01, 18.0, 10, dict(lpp=2, dynamic=False, big_scan=True)),
          ("C4", 0.005, 12.0, 6, dict(lpp=2, dynamic=False, big_scan=True)),
          ("C5", 0.002, 24.0, 6, dict(lpp=2, dynamic=True, big_scan=True))]
 
