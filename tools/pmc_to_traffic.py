@@ -24,11 +24,13 @@ def main():
         tok = line.split()
         first = next((k for k, x in enumerate(tok) if "=" in x), len(tok))
         name, kv = " ".join(tok[:first]), tok[first:]
-        mode = re.search(r"k_density<\d+,\s*(\d)>", name)  # pass A variants: 0 sweep, 1 sweep + superset list, 2 walk
+        # pass A variants: 0 sweep, 1 sweep + superset list, 2 walk (k_density_sweep_w: the large-channel form of 0 / 1)
+        mode = re.search(r"k_density(?:_sweep_w)?<\d+,\s*(\d)>", name)
         name = re.sub(r"<.*", "", name)
         if mode:
             name += {"0": "", "1": "_build", "2": "_walk"}[mode.group(1)]
         # the large-channel forms of the passes are launched under the names of the passes (bench.py's kernels_ms)
+        name = name.replace("k_density_sweep_w", "k_density")
         name = {"k_density_w": "k_density_walk", "k_kgc_w": "k_kgc", "k_forces_w": "k_forces"}.get(name, name)
         v = {}
         for item in kv:
