@@ -232,7 +232,7 @@ def main():
                 a = run_case(capi, cfg, geo, aux_name, dict(WORKLOADS[aux_name]), aux_steps, 40, 16)[0]
                 out["aux"][aux_name] = {k: a[k] for k in ("value", "ms_per_step", "roofline", "kernels_ms", "workload", "tuning")}
                 out["aux"][aux_name]["window"] = (f"{aux_steps} steps right after a developed start; sustained figures of full "
-                                                  "physical runs: DESIGN.md section 4 / profiles/r01_longrun_*.json")
+                                                  "physical runs (about 10 % lower: disordered particles idle more lanes): DESIGN.md section 4 / profiles/r02_longrun_*.json")
             except Exception as e:  # never let the side measurements break the headline line
                 out["aux"][aux_name] = {"error": repr(e)}
         # second half of the north-star metric: u(y) L2 vs the analytic parabola after the reference's full run
