@@ -2372,8 +2372,8 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const Clock *clk, int q,
 // between the layout is frozen: each rank sends the new state of a fixed list of boundary particles (send_idx) and the
 // receiver writes it into fixed slots (recv_slot); the lists are rebuilt with the layout.  Per step:
 //   passes A..E -> k_slab_seal2 -> [max all-reduce of {max|v|, max drift}] -> k_slab_decide -> k_slab_pack2
-//   -> [message A to both ring neighbours] -> k_slab_unpack2 -> {re-binning chain, k_slab_sendlist: only when the clock
-//   says so} -> [message B: the ids of my send lists] -> k_slab_recvslots
+//   -> [to both ring neighbours: message A, and message B = the ids of the send lists made in the PREVIOUS step]
+//   -> k_slab_recvslots (new ids only) -> k_slab_unpack2 -> {re-binning chain, k_slab_sendlist: only when the clock says so}
 // Ownership goes by the binned column (Grid::own_by_cell).  A particle that crosses a slab boundary changes owner at
 // the next re-binning: both ranks hold it (the old owner keeps everything in its window), the new owner names it in
 // its id list and the old owner finds its copy through slot_of_id.
@@ -2564,18 +2564,21 @@ __global__ void k_slab_seal_ids(const Clock *clk, int q, SlabPack p, SlabLists L
     }
 }
 
-// message B, receiving side: where do the particles the neighbours will keep sending live here?
+// message B, receiving side: where do the particles the neighbours will keep sending live here?  The ids travel with the
+// NEXT step's message A (one exchange per step instead of two) and are looked at before that message is unpacked; a header
+// of -1 says the lists of the cycle stay.  Not tied to the step slot being active: the slot after the loop's last step
+// still delivers the ids that step made.
 __global__ __launch_bounds__(kBlock) void k_slab_recvslots(const Clock *clk, int q, SlabPack p, SlabLists L, const int *ids_l,
                                                            const int *ids_r, const int *id_of_slot, int *flags, int force)
 {
-    if (!force && (!clk->run[q] || !clk->rebuild_now)) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= 2 * p.msg_cap) return;
     const int side = i < p.msg_cap ? 0 : 1, sl = i - side * p.msg_cap;
     const int *ids = side ? ids_r : ids_l;
     const int cnt = ids[0];
+    if (!force && cnt < 0) return;
     if (sl == 0) {
-        if (cnt < 0 || cnt > p.msg_cap) atomicOr(flags, 2);
+        if (cnt < 0 || cnt > p.msg_cap) atomicOr(flags, 2);  // (force: the first lists of a run must be there)
         L.recv_cnt[side] = max(0, min(cnt, p.msg_cap));
     }
     if (sl >= cnt || sl >= p.msg_cap) return;

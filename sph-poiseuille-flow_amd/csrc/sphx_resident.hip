@@ -1981,9 +1981,9 @@ SPHX_EXPORT int sphx_slab_comm_init(sphx_ctx *c, const void *id_bytes)
     SPHX_CATCH
 }
 
-// The exchange pattern of sphx_slab_run on a communicator of ONE rank (its own neighbour on both sides): two sends and two
-// receives in one group -- the receives must be served in the order of the sends, which is what the two-rank ring relies
-// on -- then the 16-byte all-reduce(max).  Checks the dlopen'ed entry points, enum values and stream use on this machine.
+// The exchange patterns of sphx_slab_run on a communicator of ONE rank (its own neighbour on both sides): two sends and two
+// receives in one group, then four and four with both element types (a skinned step) -- the receives must be served in the
+// order of the sends, which is what the two-rank ring relies on -- then the 16-byte all-reduce(max).  Checks the dlopen'ed entry points, enum values and stream use on this machine.
 SPHX_EXPORT int sphx_comm_selftest(void)
 {
     SPHX_TRY
@@ -2018,6 +2018,24 @@ SPHX_EXPORT int sphx_comm_selftest(void)
         };
         ring(sl.get(), sr.get(), rl.get(), rr.get(), ncclDouble);
         ring(il.get(), ir.get(), jl.get(), jr.get(), ncclInt32);
+        SPHX_HIP(hipMemcpyAsync(got_l.data(), rl.get(), n * sizeof(double), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipMemcpyAsync(got_r.data(), rr.get(), n * sizeof(double), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipMemcpyAsync(gi_l.data(), jl.get(), n * sizeof(int), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipMemcpyAsync(gi_r.data(), jr.get(), n * sizeof(int), hipMemcpyDeviceToHost, st));
+        SPHX_HIP(hipStreamSynchronize(st));
+        const bool ok_two = got_r == hl && got_l == hr && gi_r == kl && gi_l == kr;
+        // ... and the exchange of a skinned step: both messages and both id lists in ONE group (four sends, four receives)
+        rl.zero(st); rr.zero(st); jl.zero(st); jr.zero(st);
+        R.check(R.GroupStart(), "ncclGroupStart");
+        R.check(R.Send(sl.get(), n, ncclDouble, 0, comm, st), "ncclSend");
+        R.check(R.Send(sr.get(), n, ncclDouble, 0, comm, st), "ncclSend");
+        R.check(R.Send(il.get(), n, ncclInt32, 0, comm, st), "ncclSend");
+        R.check(R.Send(ir.get(), n, ncclInt32, 0, comm, st), "ncclSend");
+        R.check(R.Recv(rr.get(), n, ncclDouble, 0, comm, st), "ncclRecv");
+        R.check(R.Recv(rl.get(), n, ncclDouble, 0, comm, st), "ncclRecv");
+        R.check(R.Recv(jr.get(), n, ncclInt32, 0, comm, st), "ncclRecv");
+        R.check(R.Recv(jl.get(), n, ncclInt32, 0, comm, st), "ncclRecv");
+        R.check(R.GroupEnd(), "ncclGroupEnd");
         R.check(R.AllReduce(v.get(), vg.get(), 2, ncclDouble, ncclMax, comm, st), "ncclAllReduce");
         SPHX_HIP(hipMemcpyAsync(got_l.data(), rl.get(), n * sizeof(double), hipMemcpyDeviceToHost, st));
         SPHX_HIP(hipMemcpyAsync(got_r.data(), rr.get(), n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -2026,7 +2044,7 @@ SPHX_EXPORT int sphx_comm_selftest(void)
         SPHX_HIP(hipMemcpyAsync(gv, vg.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         SPHX_HIP(hipStreamSynchronize(st));
         // what went to the left arrives "from the right" and vice versa
-        ok = got_r == hl && got_l == hr && gi_r == kl && gi_l == kr && gv[0] == hv[0] && gv[1] == hv[1];
+        ok = ok_two && got_r == hl && got_l == hr && gi_r == kl && gi_l == kr && gv[0] == hv[0] && gv[1] == hv[1];
     } catch (...) {
         (void)R.CommDestroy(comm);
         if (st) (void)hipStreamDestroy(st);
@@ -2084,11 +2102,14 @@ void slab_phase2(sphx_ctx *c)  // global maxima known: clock + re-binning decisi
     launch(c, "k_slab_seal_msg", k_slab_seal_msg, dim3(1), dim3(1), (const Clock *)clk, q, p, c->lists);
 }
 
-void slab_phase3(sphx_ctx *c)  // message A arrived: refresh the halo copies, or re-bin and make the lists of the next cycle
+void slab_phase3(sphx_ctx *c)  // message A arrived (and with it the ids of the lists the neighbours made in the previous step):
+                               // refresh the halo copies, or re-bin and make the lists of the next cycle
 {
     const int q = c->cur, qf = q | kOnlyIfRebuild;
     Clock *clk = c->clock.get();
     const FluidSet d = slab_new_state(c);
+    launch(c, "k_slab_recvslots", k_slab_recvslots, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock), (const Clock *)clk, q,
+           c->pack, c->lists, (const int *)c->ids_r_[0].get(), (const int *)c->ids_r_[1].get(), (const int *)d.id, c->flags.get(), 0);
     launch(c, "k_slab_unpack2", k_slab_unpack2, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock), (const Clock *)clk, q,
            c->grid, d, c->pack, c->lists, (const double *)c->msg_rl.get(), (const double *)c->msg_rr.get(), c->n_new.get(),
            c->flags.get());
@@ -2105,12 +2126,8 @@ void slab_phase3(sphx_ctx *c)  // message A arrived: refresh the halo copies, or
     launch(c, "k_slab_seal_ids", k_slab_seal_ids, dim3(1), dim3(1), (const Clock *)clk, q, c->pack, c->lists, 0);
 }
 
-void slab_phase4(sphx_ctx *c)  // message B arrived
+void slab_phase4(sphx_ctx *c)  // host bookkeeping of the step (the ids made in phase 3 travel with the next step's message A)
 {
-    const int q = c->cur;
-    launch(c, "k_slab_recvslots", k_slab_recvslots, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock),
-           (const Clock *)c->clock.get(), q, c->pack, c->lists, (const int *)c->ids_r_[0].get(), (const int *)c->ids_r_[1].get(),
-           (const int *)slab_new_state(c).id, c->flags.get(), 0);
     SPHX_HIP(hipGetLastError());
     c->cur ^= 1;
     c->slab_steps_enqueued += 1;
@@ -2167,6 +2184,19 @@ SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
         R.check(R.Recv(from_l, count, ty, left, c->comm, st), "ncclRecv");
         R.check(R.GroupEnd(), "ncclGroupEnd");
     };
+    // the exchange of a skinned step: message A and the list ids of the previous step in ONE group
+    auto ring_step = [&]() {
+        R.check(R.GroupStart(), "ncclGroupStart");
+        R.check(R.Send(sl, n_msg, ncclDouble, left, c->comm, st), "ncclSend");
+        R.check(R.Send(sr, n_msg, ncclDouble, right, c->comm, st), "ncclSend");
+        R.check(R.Send(c->ids_s_[0].get(), n_ids, ncclInt32, left, c->comm, st), "ncclSend");
+        R.check(R.Send(c->ids_s_[1].get(), n_ids, ncclInt32, right, c->comm, st), "ncclSend");
+        R.check(R.Recv(rr, n_msg, ncclDouble, right, c->comm, st), "ncclRecv");
+        R.check(R.Recv(rl, n_msg, ncclDouble, left, c->comm, st), "ncclRecv");
+        R.check(R.Recv(c->ids_r_[1].get(), n_ids, ncclInt32, right, c->comm, st), "ncclRecv");
+        R.check(R.Recv(c->ids_r_[0].get(), n_ids, ncclInt32, left, c->comm, st), "ncclRecv");
+        R.check(R.GroupEnd(), "ncclGroupEnd");
+    };
     // arm the clock with the global max |v| of the current state
     slab_local_maxima(c);
     R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
@@ -2186,9 +2216,8 @@ SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
             slab_phase1(c);
             R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
             slab_phase2(c);
-            ring(sl, sr, rl, rr, n_msg, ncclDouble);
+            ring_step();
             slab_phase3(c);
-            ring(c->ids_s_[0].get(), c->ids_s_[1].get(), c->ids_r_[0].get(), c->ids_r_[1].get(), n_ids, ncclInt32);
             slab_phase4(c);
         }
     }
@@ -2285,15 +2314,15 @@ SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int
             slab_phase2(c);
         }
         done(&sphx_ctx::ev_received);  // (reused: "my maxima have been read by me, my message A is complete")
-        for (int r = 0; r < n; ++r) {  // message A in, re-binning chain, message B out
+        for (int r = 0; r < n; ++r) {  // message A and the ids of the previous step's lists in
             wait_others(r, &sphx_ctx::ev_received);
             copy_msgs(r);
-            slab_phase3(ctxs[r]);
-        }
-        done(&sphx_ctx::ev_computed);
-        for (int r = 0; r < n; ++r) {  // message B in
-            wait_others(r, &sphx_ctx::ev_computed);
             copy_ids(r);
+        }
+        done(&sphx_ctx::ev_computed);  // (reused: "I have taken what the neighbours addressed to me")
+        for (int r = 0; r < n; ++r) {  // halo refresh or re-binning chain; the lists / ids of the next cycle overwrite the old ones
+            wait_others(r, &sphx_ctx::ev_computed);
+            slab_phase3(ctxs[r]);
             slab_phase4(ctxs[r]);
         }
         done(&sphx_ctx::ev_received);

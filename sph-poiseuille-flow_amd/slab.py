@@ -375,8 +375,8 @@ def bench_main(args, rank, world, local_rank):
         nt, lay = parts["n_total"], eng.layout()
         eng.close()
         alg = (528 * parts["n_fluid"] + 120 * parts["n_wall"]) * steps / seconds / 1e9
-        loop = ("native step loop in libsphx over RCCL: re-binning every 5th step, per step two ncclSend/ncclRecv rings "
-                "(state, list ids) + one 16-byte ncclAllReduce(max)"
+        loop = ("native step loop in libsphx over RCCL: re-binning every 5th step, per step one group of ncclSend/ncclRecv "
+                "with both ring neighbours (state + list ids) and one 16-byte ncclAllReduce(max)"
                 if use_native else f"Python step loop over torch.distributed[{dist.get_backend()}], re-binning every step"
                                    + (" (messages staged through host memory)" if dist.get_backend() != "nccl" else "")
                                    + (f" -- native RCCL loop unavailable: {why_not}" if native and why_not else ""))

@@ -58,6 +58,7 @@ def test_slab_hip_two_ranks_half_million_particles():
 @pytest.mark.parametrize("world,dp,DL,steps,kw", [
     (2, 0.05, 3.0, 7, dict(rebuild_every=1)),                # re-binning every step: the protocol of compute / finish
     (2, 0.05, 3.0, 23, dict()),                              # default: every 5th step, frozen layouts in between
+    (2, 0.05, 3.0, 23, dict(calls=[5, 5, 1, 9, 3])),         # ... in five calls, two of them ending on a re-binning step
     (3, 0.05, 4.5, 23, dict(rebuild_every=4)),
     (2, 0.04, 3.0, 17, dict(rebuild_every=8, skin_h=0.05)),  # skin far too thin: the drift bound triggers the re-binnings
     (4, 0.01, 6.0, 12, dict()),
@@ -76,9 +77,13 @@ def test_slab_native_ring_in_one_process(world, dp, DL, steps, kw):
     slab = importlib.import_module("sph-poiseuille-flow_amd.slab")
     prm, parts = make_case(pkg.config, pkg.geometry, dp=dp, DL=DL, jitter=0.2, seed=11, developed=True, end_time=1e9)
     nf, nt = parts["n_fluid"], parts["n_total"]
+    kw = dict(kw)
+    calls = kw.pop("calls", [steps])  # the run in several calls: the ids of a re-binning in a call's last step travel with the next call
+    assert sum(calls) == steps
     engines = [slab.HipSlabEngine(prm, parts, r, world, 0, t_end=1e9, native=True, **kw) for r in range(world)]
     try:
-        slab.HipSlabEngine.group_run(engines, steps)
+        for n_call in calls:
+            slab.HipSlabEngine.group_run(engines, n_call)
         sts = [e.sync() for e in engines]
         snaps = [e.snapshot() for e in engines]
     finally:
