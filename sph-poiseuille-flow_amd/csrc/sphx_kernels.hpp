@@ -863,11 +863,13 @@ __host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : 
 // time and pack the accepted entries with ballot + popcount, so a group's trip count is uniform: the rows in which all
 // of its lanes hold fluid candidates run a branch-free fluid body with the entries three rows ahead, the (at most one
 // mixed + the wall) rows behind them run the general body.
-// (No LDS tile here: staging the candidate positions made this pass 10 % slower at 0.5 M and at 6 M particles -- it
-// gathers 16 bytes per candidate, too little for the staging to pay.)
-template <int LPP>
+// (LDS tile: staging the candidate positions makes this pass slower at 0.5 M particles -- 50.5 against 42.3 us, it gathers
+// only 16 bytes per candidate -- and, now that the pass runs at the texture addresser's limit, 6 % faster at 6 M: used
+// where KGC and continuity use theirs.)
+template <int LPP, int TILE = 0>
 __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
-                                                  const FluidTmp &t, const Walls &w, int bid, int nblk, bool half)
+                                                  const FluidTmp &t, const Walls &w, int bid, int nblk, bool half,
+                                                  double2 *c_pos = nullptr)
 {
     SPHX_PASS_INDEX_AT(bid, nblk);
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
@@ -878,6 +880,12 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     const double dt = clk->dt;
     if (!clk->run[q]) return;
     const bool active = i < clk->n;
+    TileMap tm{0, 0, 0, 0, 0, 0};
+    if (TILE > 0) {  // candidate positions of the workgroup's three-column neighbourhood staged in LDS (see tile_ranges)
+        tm = tile_ranges<LPP>(g, s, blk, clk->n, TILE);
+        for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) c_pos[sl] = s.pos[tm.index(sl)];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
     const int row_base = tid - sub;
     const int half_shift = gbase & 31;
@@ -923,6 +931,22 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
         };
         int ea = e_row0, eb = rows_fl > 1 ? e_row1 : e_row0, ec = entry(2);
         int ed = entry(3), ee = entry(4), ef = entry(5);
+        if (TILE > 0) {  // positions from the tile (a few cycles away): only the entries run ahead
+            auto fetch = [&](int k) -> double2 {  // (early return, not if/else: see k_kgc_w)
+                const int slot = tm.slot(k);
+                if (slot >= 0) return c_pos[slot];
+                return s.pos[k];
+            };
+            for (int m = 0; m < rows_fl; m += 3) {
+                const int eg = entry(m + 6), eh = entry(m + 7), ei = entry(m + 8);
+                row(ea, fetch(ea));
+                if (m + 1 < rows_fl) row(eb, fetch(eb));
+                if (m + 2 < rows_fl) row(ec, fetch(ec));
+                ea = ed; eb = ee; ec = ef;
+                ed = eg; ee = eh; ef = ei;
+            }
+            return;
+        }
         double2 pa = s.pos[ea], pb = s.pos[eb], pc = s.pos[ec];
         for (int m = 0; m < rows_fl; m += 3) {
             const int eg = entry(m + 6), eh = entry(m + 7), ei = entry(m + 8);
@@ -1161,12 +1185,14 @@ __global__ __launch_bounds__(kBlock) void k_density_sweep_w(const Clock *clk, in
     density_sweep_body_w<LPP, MODE>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true);
 }
 
-template <int LPP>
+template <int LPP, int TILE = 0>
 __global__ __launch_bounds__(kBlock) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                       FluidTmp t, Walls w, int cond_fresh)
 {
+    constexpr int kSlots = TILE > 0 ? TILE : 1;
+    __shared__ double2 c_pos[kSlots];
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
-    density_walk_body<LPP>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true);
+    density_walk_body<LPP, TILE>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true, c_pos);
 }
 
 // pass B (see k_kgc)

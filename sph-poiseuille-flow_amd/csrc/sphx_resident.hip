@@ -162,6 +162,7 @@ struct sphx_ctx {
     // (k_continuity_density).  The neighbour list and the {Vol, p, rho_h, rho} records then exist once per state parity:
     // tmp_par[p] is `tmp` with the buffers of parity p; out_par = the parity of the last executed step (its Vol).
     bool fuse_ea = false;
+    bool lds_tiles_a = false;    // pass A's walk gathers the candidate positions from an LDS tile
     bool sweep_kernels = false;  // pass A's cell sweep in its large-channel form (k_density_sweep_w)
     int n_in = 1;                // dual-rate loop: inner sub-steps per step slot (1 = the reference's single-rate loop)
     DevBuf<double2> vel2;        // ... and the second velocity array its sub-steps alternate with
@@ -301,7 +302,10 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             const int cond = dmode == 2 ? -1 : 0;
             if (dmode == 3) sweep("k_density_build", std::integral_constant<int, 1>{}, 1);
             if (!walk_w) launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
-            else if constexpr (LPP <= 8) launch(c, "k_density_walk", k_density_w<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+            else if constexpr (LPP <= 8) {
+                if (c->lds_tiles_a) launch(c, "k_density_walk", k_density_w<LPP, tile_slots(LPP)>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+                else launch(c, "k_density_walk", k_density_w<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+            }
         }
     }
     // large channels (few lanes per particle) run the "_w" forms of passes B, CD and E, see sphx_kernels.hpp
@@ -1022,6 +1026,7 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");  // (65 k particles: 46.8 with, 46.3 us/step without;
     // 100-130 k: equal; 194 k: 96.4 / 97.1; 259 k: 117.3 / 119.5; 360 k: 145.8 / 151.0 -- kept on at every size)
     c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && c->nf >= 2000000;
+    c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 40;  // measured at C2: 10 -> 25.4, 40 -> 25.1, 80 -> 24.8 us/step
     if (c->spg & 1) c->spg += 1;
 
@@ -1654,6 +1659,7 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     c->sweep_kernels = c->walk_kernels && !std::getenv("SPHX_NO_SWEEP_KERNELS");
     c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");
     c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_local >= 2000000;
+    c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
     c->spg = 2;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else SPHX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
