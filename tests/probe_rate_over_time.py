@@ -1,14 +1,16 @@
 """Manual probe: step time of a physical run from the lattice at rest, in windows (is the developed flow slower per step than
-the jittered analytic start bench.py times?).  python tests/probe_rate_over_time.py [dp DL t_end n_windows]"""
+the jittered analytic start bench.py times?).  python tests/probe_rate_over_time.py [dp DL t_end n_windows [dynamic_rebin]]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 dp, DL, t_end, nwin = (float(sys.argv[1]), float(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0.005, 12.0, 2.0, 10)
+dyn = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 prm = pkg.config.params_from_values(dp=dp, DL=DL, end_time=t_end, output_interval=t_end)
 parts = pkg.geometry.init_particles(prm)
 nf, nt = parts["n_fluid"], parts["n_total"]
-with pkg.capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"]) as ctx:
+with pkg.capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"], dynamic_rebin=dyn) as ctx:
     step0, forced0 = 0, 0
+    t_all = time.perf_counter()
     for w in range(nwin):
         t0 = time.perf_counter()
         st = ctx.advance(t_end * (w + 1) / nwin)
@@ -18,3 +20,4 @@ with pkg.capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"],
         n = st["step"] - step0
         print(f"t={st['t']:.3f} steps={n} us/step={1e6*dt/max(n,1):.1f} pairs/particle={npairs/nf:.2f} forced+={pol['forced_rebuilds']-forced0} vmax={st['vmax']:.3f}", flush=True)
         step0, forced0 = st["step"], pol["forced_rebuilds"]
+    print(f"dynamic_rebin={dyn}: {st['step']} steps in {time.perf_counter() - t_all:.2f} s = {1e6 * (time.perf_counter() - t_all) / st['step']:.1f} us/step", flush=True)
