@@ -83,7 +83,7 @@ struct Clock {
     int n;                       // particles currently held (fluid, incl. slab halo copies)
     double drift;                // largest distance of any particle from where it was when the grid was built
     int need_rebuild;            // 1: drift exceeded half the cell skin -> the loop stopped, host must re-bin
-    int pad;
+    int n_rebins;                // dynamic contexts / skinned slabs: re-binnings decided by the clock so far (statistics)
     // "dynamic" contexts (large channels): the device itself decides when to re-bin -- at the K-th step since the
     // last re-binning or as soon as the drift exceeds skin/2 -- and the re-binning kernels of every step skip
     // themselves unless rebuild_now is set; no host round trip, need_rebuild is never raised
@@ -1521,6 +1521,7 @@ __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phy
         c.pos_count = rb ? 0 : c.pos_count + 1;
         c.drift = rb ? 0.0 : drift;
         if (by_drift) c.n_drift_rebuilds += 1;
+        if (rb) c.n_rebins += 1;
     } else if (drift >= 0.0) {
         c.drift = rebuilt ? 0.0 : drift;
         // every step sweeps the cells the particles were BINNED into; that finds all neighbours only while no

@@ -90,6 +90,7 @@ struct sphx_ctx {
     int out_lay = 0;             // layout the per-step outputs (rho,p,force,Vol,B) are stored in; when it is not
                                  // `lay`, tmp.src_of maps current slots to the slots of those outputs
     int64_t n_forced_rebuilds = 0, last_forced_step = 0;
+    int64_t n_rebins = 0, epoch_n_rebins = 0;  // re-binnings executed by step slots of the static schedule (not the forced ones)
     int64_t pending_target = 0;  // step count the sphx_ctx_enqueue_steps calls since the last sync aim for
     bool have_step_outputs = false;
 
@@ -553,7 +554,7 @@ void track_step(sphx_ctx *c)
     c->out_lay = c->lay;  // outputs are stored in the layout the step ran in; after a rebuild tmp.src_of maps to it
     c->out_par = c->cur;  // ... and (fuse_ea) in the record buffers of the step's state parity
     c->cur ^= 1;
-    if (rebuild) { c->lay ^= 1; c->pos = 0; }
+    if (rebuild) { c->lay ^= 1; c->pos = 0; c->n_rebins += 1; }
     else c->pos += 1;
 }
 
@@ -677,6 +678,7 @@ void set_epoch(sphx_ctx *c)
     c->epoch_step = c->h_clock->step;
     c->epoch_cur = c->cur; c->epoch_lay = c->lay; c->epoch_pos = c->pos; c->epoch_out_lay = c->out_lay;
     c->epoch_out_par = c->out_par;
+    c->epoch_n_rebins = c->n_rebins;
     c->prov_step = c->epoch_step;
 }
 
@@ -707,6 +709,7 @@ void read_clock(sphx_ctx *c)
     const int64_t executed = (int64_t)c->h_clock->step - c->epoch_step;
     c->cur = c->epoch_cur; c->lay = c->epoch_lay; c->pos = c->epoch_pos; c->out_lay = c->epoch_out_lay;
     c->out_par = c->epoch_out_par;
+    c->n_rebins = c->epoch_n_rebins;
     c->prov_step = c->epoch_step;
     if (executed > 0) {
         int64_t left = executed;
@@ -718,7 +721,7 @@ void read_clock(sphx_ctx *c)
             if (c->prov_step >= c->cool_until && left > 4 * c->rebuild_every) {
                 // steady interval: (cur, lay, pos) repeats every 2K steps -> skip whole periods
                 const int64_t period = 2 * c->rebuild_every, skip = ((left - 1) / period - 1) * period;
-                if (skip > 0) { c->prov_step += skip; left -= skip; }
+                if (skip > 0) { c->prov_step += skip; left -= skip; c->n_rebins += 2 * (skip / period); }
             }
             track_step(c);
             --left;
@@ -1538,6 +1541,18 @@ SPHX_EXPORT int sphx_ctx_tuning(sphx_ctx *c, int *lanes_per_particle, int *steps
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     if (lanes_per_particle) *lanes_per_particle = c->lpp;
     if (steps_per_graph) *steps_per_graph = c->spg;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_ctx_schedule(sphx_ctx *c, int *fuse_ea, int *tail_clock, int *dynamic, int64_t *rebins)
+{
+    SPHX_TRY
+    require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    if (fuse_ea) *fuse_ea = c->fuse_ea ? 1 : 0;
+    if (tail_clock) *tail_clock = c->tail_clock ? 1 : 0;
+    if (dynamic) *dynamic = c->dyn ? 1 : 0;
+    if (rebins) *rebins = c->dyn ? (int64_t)c->h_clock->n_rebins : c->n_rebins;
     return SPHX_OK;
     SPHX_CATCH
 }

@@ -1,0 +1,108 @@
+"""-m gpu: the code path behind bench.py's headline value, particle by particle against the oracle ACROSS its
+re-binnings.
+
+bench.py's C2 line runs the DEFAULT context: no lanes_per_particle, no rebuild_every -- 32 lanes per particle on the
+compact kernels, cells re-binned every 16th step (K = 16), pass E of step n and pass A of step n+1 in one launch
+(k_continuity_density, `fuse_ea`).  The other resident tests reach <= 10 steps on that context, i.e. they stop short
+of its first scheduled re-binning (step 16: k_continuity with the cell histogram -> k_clock_scan -> k_scatter ->
+k_reorder -> the stand-alone cell-sweeping k_density<32, build>).  Here C2 (dp 0.025, DL 3: 5 760 particles, the
+metric's own configuration) and C1 (dp 0.04, DL 3: config.ini's size class) run 20 and 35 steps -- one resp. two
+scheduled re-binnings -- and every output of the step is compared with oracle.run on the same seeded state: the
+nine fields, t, dt, max|v|, the pair count of the rebuilt neighbour structure, the wall shear.
+
+Reference loop: SPH_Poiseuille.m:250-292 (step), :529-568 (cell sort), neighbor.c:312-392 (pair search).
+
+Tolerances.  The two sides evaluate the same formulas in a different summation order.  The error norm is
+max|a - b| / max|b| per field (entries that cancel to ~0 do not count against a field).  Measured on MI355X (round 3,
+seed 21), largest field error: C2 7.1e-13 @20 steps, 1.3e-12 @35; C1 4.5e-13 @20, 7.7e-13 @35 (force / p / drho_dt;
+pos 5e-16, rho / Vol / B 1e-14, t and dt < 1e-15): round-off grows slowly in this norm.  The bound asserted is
+RTOL[n_steps] -- two decades above the measured value, eight decades below any formula or neighbour-set error (a single
+missed or doubled neighbour changes rho by ~1e-2 relative).  Integer work (pair count, step count) is exact.
+"""
+import numpy as np
+import pytest
+
+from helpers import make_case
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
+RTOL = {20: 1e-10, 35: 1e-10, 100: 1e-9}
+#        name  dp     DL   lattice jitter
+CASES = [("C2", 0.025, 3.0, 0.2), ("C1", 0.04, 3.0, 0.2)]
+
+
+def _errors(got, ref):
+    """max |a - b| / max|b| per field: one number per field, insensitive to entries that cancel to ~0."""
+    out = {}
+    for k in FIELDS:
+        a, b = np.asarray(got[k]), np.asarray(ref[k])
+        assert a.shape == b.shape and np.all(np.isfinite(a)), k
+        out[k] = float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+    return out
+
+
+@pytest.mark.parametrize("n_steps", [20, 35, 100])
+@pytest.mark.parametrize("name,dp,DL,jitter", CASES, ids=[c[0] for c in CASES])
+def test_default_headline_context_matches_oracle_across_rebinning(name, dp, DL, jitter, n_steps, cfgmod, geom, capi,
+                                                                  oracle, capsys):
+    prm, parts = make_case(cfgmod, geom, dp=dp, DL=DL, jitter=jitter, seed=21, developed=True)
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
+                      t_end=1e9) as ctx:  # every tuning knob left at its default: this is bench.py's context
+        tun, pol = ctx.tuning(), ctx.grid_policy()
+        sched = ctx.schedule()
+        st = ctx.advance(1e9, max_steps=n_steps)
+        got = ctx.download()
+        tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
+        pol_after, sched_after = ctx.grid_policy(), ctx.schedule()
+    # the configuration the headline number is measured on
+    assert tun["lanes_per_particle"] == 32, tun
+    assert pol["rebuild_every"] == 16, pol
+    assert sched["fuse_ea"] == 1, sched
+    # ... and the run went through its scheduled re-binnings (none of them forced by the drift bound)
+    assert sched_after["rebins"] - sched["rebins"] == n_steps // 16 >= 1, (sched, sched_after)
+    assert pol_after["forced_rebuilds"] == 0, pol_after
+
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=n_steps, enable_sort=False)
+    rs = ref["stats"]
+    assert st["step"] == n_steps == rs["steps"]
+    rtol = RTOL[n_steps]
+    err = _errors(got, ref)
+    with capsys.disabled():
+        print(f"\n[headline parity] {name} n={nt} steps={n_steps}: max rel err "
+              + " ".join(f"{k}={v:.1e}" for k, v in err.items())
+              + f" | t {abs(st['t'] - rs['t']) / rs['t']:.1e} dt {abs(st['dt_last'] - rs['dt_last']) / rs['dt_last']:.1e}")
+    assert abs(st["t"] - rs["t"]) <= 1e-12 * rs["t"]
+    assert abs(st["dt_last"] - rs["dt_last"]) <= rtol * rs["dt_last"]
+    assert abs(st["vmax"] - rs["vmax"]) <= rtol * rs["vmax"]
+    for k, e in err.items():
+        assert e <= rtol, f"{name}:{k}@{n_steps}: {e:.3e} > {rtol:.0e}"
+    assert npairs == rs["n_pairs_last"], (npairs, rs["n_pairs_last"])  # exact: same neighbour set after re-binning
+    for a, b in ((tb, rs["tau_bottom"]), (tt, rs["tau_top"])):
+        assert abs(a - b) <= 10 * rtol * max(abs(rs["tau_bottom"]), abs(rs["tau_top"]))
+    assert np.all(got["pos"][:nf, 0] >= 0) and np.all(got["pos"][:nf, 0] <= prm.DL)
+
+
+def test_headline_context_from_the_reference_lattice(cfgmod, geom, capi, oracle):
+    """C2 from the reference's own initial state (lattice at rest, SPH_Poiseuille.m:95-119), 35 steps = two re-binnings
+    on the default context.  On the pristine lattice most sums cancel exactly, so the fields are compared with an
+    absolute floor on the field's own scale (p0*dp for pressure-driven quantities)."""
+    prm = cfgmod.params_from_values(dp=0.025, DL=3.0)
+    parts = geom.init_particles(prm)
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    assert (nf, nt) == (4800, 5760)
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=35, enable_sort=False)
+    with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
+                      t_end=1e9) as ctx:
+        st = ctx.advance(1e9, max_steps=35)
+        got = ctx.download()
+        _, _, npairs = ctx.monitor(tau=False, pairs=True)
+        assert ctx.grid_policy()["rebuild_every"] == 16 and ctx.schedule()["rebins"] >= 2
+    assert st["step"] == 35 and abs(st["t"] - ref["stats"]["t"]) <= 1e-12 * ref["stats"]["t"]
+    assert npairs == ref["stats"]["n_pairs_last"]
+    scale = dict(pos=prm.DL, vel=prm.gravity_g * st["t"], rho=prm.rho0, p=prm.p0 * 1e-3, drho_dt=prm.rho0,
+                 force=prm.p0 * prm.dp, force_prior=prm.p0 * prm.dp, Vol=prm.dp ** 2, B=1.0)
+    for k in FIELDS:
+        e = float(np.max(np.abs(got[k] - ref[k]))) / scale[k]
+        assert e <= 1e-9, f"C2 lattice:{k}: {e:.3e}"
