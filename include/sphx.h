@@ -261,7 +261,11 @@ int sphx_ctx_info(sphx_ctx *ctx, int *n_fluid, int *n_wall, int *n_cell_x, int *
  * ---------------------------------------------------------------------------------------------- */
 
 /* Create rank `rank` of `n_ranks` from the GLOBAL host state (same arguments as sphx_ctx_create on
- * every rank).  halo_cols >= 4. */
+ * every rank).  halo_cols >= 4.  prm->rebuild_every selects the protocol: 1 = the slab re-bins every step and is
+ * driven by the caller (sphx_slab_local_vmax / _prepare / _compute / _finish below, any transport); any other value
+ * (0 = auto: 5) = skinned slab for the library's own loops only (sphx_slab_run over RCCL, sphx_slab_group_run): it
+ * re-bins every K-th step or when the device sees the drift bound hit, and the four caller-driven calls refuse it
+ * with SPHX:Slab:protocol. */
 int sphx_slab_create(sphx_ctx **ctx, const sphx_params *prm, int n_fluid, int n_total,
                      const double *pos, const double *vel, const double *drho_dt, const double *mass,
                      const double *wall_vel, double t0, int64_t step0, int rank, int n_ranks,
@@ -291,14 +295,25 @@ int sphx_slab_finish(sphx_ctx *ctx, const double *recv_left_dev, const double *r
  * sphx_slab_group_run: all slabs of the ring in ONE process on one device -- the same loop with device-to-device
  * copies as the transport (tests and rehearsals on a one-GPU box).  Both return without waiting; sphx_slab_sync
  * waits and reports. */
+/* SPHX_OK when librccl can be loaded with every entry point the native loop needs (purely local, no communication):
+ * a launcher lets all ranks agree on this BEFORE anyone enters the collective sphx_slab_comm_init. */
+int sphx_comm_available(void);
 int sphx_comm_unique_id(void *id_bytes, int capacity);
 /* Diagnostic: runs the exchange pattern of sphx_slab_run (grouped sends / receives, the all-reduce) on a one-rank
  * communicator on the current device and checks what comes back.  SPHX_OK, or an error naming the RCCL call that failed. */
 int sphx_comm_selftest(void);
+/* The same calls captured into a hipGraph and replayed (one-rank communicator): can this RCCL be captured?  What
+ * sphx_slab_graph_prepare relies on. */
+int sphx_comm_selftest_graph(void);
 int sphx_slab_comm_init(sphx_ctx *ctx, const void *id_bytes);
 int sphx_slab_comm_destroy(sphx_ctx *ctx);
 int sphx_slab_run(sphx_ctx *ctx, double t_target, int64_t n_steps);
 int sphx_slab_group_run(sphx_ctx **ctxs, int n_ranks, double t_target, int64_t n_steps);
+/* Capture ten whole steps of the native loop -- kernels and the RCCL calls (n_ranks = 1: the context of this process's
+ * rank) or the copies and cross-stream dependencies of an in-process ring (n_ranks >= 2) -- into one hipGraph; the two
+ * loops above then replay it for every full batch of ten steps.  Call after the loop has run at least two steps, on
+ * every rank at the same point (the graph is warmed with one idle replay, which communicates).  Skinned slabs only. */
+int sphx_slab_graph_prepare(sphx_ctx **ctxs, int n_ranks);
 /* Wait for the stream; fails if a step was enqueued after the loop had stopped or a buffer overflowed. */
 int sphx_slab_sync(sphx_ctx *ctx, sphx_status *status);
 /* Host copy of the slab's current particles (owned + halo copies); owned[i] = 1 for owned ones. */

@@ -52,8 +52,8 @@ EXPORTS = [
     "sphx_ctx_download", "sphx_ctx_monitor", "sphx_ctx_neighbor_list", "sphx_ctx_profile_enable",
     "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_substeps", "sphx_ctx_schedule", "sphx_ctx_grid_policy", "sphx_ctx_time_kernel",
     "sphx_slab_create", "sphx_slab_layout", "sphx_slab_local_vmax", "sphx_slab_prepare", "sphx_slab_compute",
-    "sphx_slab_finish", "sphx_slab_sync", "sphx_slab_snapshot", "sphx_comm_unique_id", "sphx_comm_selftest", "sphx_slab_comm_init",
-    "sphx_slab_comm_destroy", "sphx_slab_run", "sphx_slab_group_run",
+    "sphx_slab_finish", "sphx_slab_sync", "sphx_slab_snapshot", "sphx_comm_available", "sphx_comm_unique_id", "sphx_comm_selftest", "sphx_comm_selftest_graph", "sphx_slab_comm_init",
+    "sphx_slab_comm_destroy", "sphx_slab_run", "sphx_slab_group_run", "sphx_slab_graph_prepare",
 ]
 
 _LIB = None

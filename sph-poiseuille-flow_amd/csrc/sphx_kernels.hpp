@@ -142,6 +142,8 @@ struct FluidTmp {
     double *vol;     // Vol once more, 8 bytes per particle: passes B and E gather nothing else of `a`, and pulling the
                      // 32-byte records through the caches for one double costs them ~15 % (measured the other way
                      // round: 64-byte records made them 25 % slower)
+    double *seal_out;  // skinned slabs: the tail workgroup of pass E leaves {max |v|, max drift} of the owned particles here
+                       // (the input of the step's max all-reduce), see slab_seal_tail
 };
 
 // "no value yet" in vpart when pass E carries the clock update in a tail workgroup (see continuity_tail)
@@ -765,6 +767,16 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
 // trips and code size (instruction-cache fill per launch) matters more than instruction count.
 // =================================================================================================
 
+// Large-channel kernels are launched for the CAPACITY of the arrays; a workgroup whose first particle lies beyond the
+// current population has nothing to do.  Its lanes used to request their own records like everybody else before looking
+// at the clock (the latency trick of the small channels) -- on a slab, whose capacity holds 15-20 % of slack, that was
+// 15-20 % more waves going through every pass's prologue.
+template <int LPP>
+__device__ __forceinline__ bool beyond_population(const Clock *clk, int blk)
+{
+    return blk * (kBlock / LPP) >= clk->n;
+}
+
 // A neighbour's x can be a period away from the particle's only if one of them was binned in the first or last cell
 // column and has since been wrapped; particles whose x lies within 2.5 columns of either end of the period cover every
 // such pair (a column is wider than the skin, so a particle binned in column <= 1 is still left of 2.5 columns).
@@ -872,6 +884,7 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
                                                   double2 *c_pos = nullptr)
 {
     SPHX_PASS_INDEX_AT(bid, nblk);
+    if (beyond_population<LPP>(clk, blk)) return;  // (nl_cnt of lanes beyond the population is never looked at)
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool lead = in_cap && sub == 0;
     const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
@@ -1010,6 +1023,7 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
 {
     static_assert(MODE == 0 || MODE == 1, "sweeping forms only");
     SPHX_PASS_INDEX_AT(bid, nblk);
+    if (beyond_population<LPP>(clk, blk)) return;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int ci = in_cap ? s.cell[i] : 0;
     const bool lead = in_cap && sub == 0;
@@ -1204,6 +1218,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     __shared__ double2 c_pos[kSlots];
     __shared__ double c_vol[kSlots];
     SPHX_PASS_INDEX();
+    if (beyond_population<LPP>(clk, blk)) return;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool closes = finish_half && in_cap && sub == 0;  // (see k_kgc)
     const double4 a_own = closes ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
@@ -1304,6 +1319,10 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
     __shared__ double4 c_a[kSlots], c_B[kSlots];
     SPHX_PASS_INDEX();
+    if (beyond_population<LPP>(clk, blk)) {  // (a slab's arrays have 15-20 % of slack: see beyond_population)
+        if (threadIdx.x == 0 && clk->run[q]) t.dpart[blk] = 0.0;
+        return;
+    }
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? s.vel[i] : make_double2(0.0, 0.0);
     const double4 ai = in_cap ? t.a[i] : make_double4(1.0, 0.0, 0.0, 0.0);
@@ -1597,7 +1616,47 @@ __device__ __forceinline__ void continuity_tail(Clock *clk, int q, const Phys &p
     }
 }
 
-// tail: 1 = the launch has one workgroup more than the pass needs; it runs continuity_tail
+// Skinned slabs: the local maxima the step's all-reduce needs -- max |v| and max drift of the owned particles -- are
+// reduced by a tail workgroup of pass E (same hand-over as continuity_tail: every vpart entry is its own "ready" flag)
+// instead of a one-workgroup kernel behind it.  out[0..1] = {max |v|, max drift}; a stopped loop reports zeros.
+__device__ __forceinline__ void slab_seal_tail(const Clock *clk, int q, const FluidTmp &t, int nb)
+{
+    if (!clk->run[q]) {
+        if (threadIdx.x == 0) { t.seal_out[0] = 0.0; t.seal_out[1] = 0.0; }
+        return;
+    }
+    double m = 0.0, d = 0.0;
+    int lost = 0;
+    for (int k = threadIdx.x; k < nb; k += kBlock) {
+        d = fmax(d, t.dpart[k]);  // written by pass CD, a kernel ago
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(&t.vpart[k]);
+        unsigned long long bits;
+        unsigned spins = 0;
+        while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kVpartEmpty) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) { lost = 1; break; }  // never hang the device on a protocol bug
+        }
+        if (!lost) m = fmax(m, __longlong_as_double((long long)bits));
+        __hip_atomic_store(slot, kVpartEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmax(m, __shfl_xor(m, off));
+        d = fmax(d, __shfl_xor(d, off));
+        lost |= __shfl_xor(lost, off);
+    }
+    __shared__ double s_m[kBlock / 64], s_d[kBlock / 64];
+    __shared__ int s_l[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; s_l[threadIdx.x >> 6] = lost; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); lost |= s_l[k]; }
+        t.seal_out[0] = lost ? INFINITY : sqrt(m);  // (a lost hand-over poisons the maximum: the clock raises DIVERGED)
+        t.seal_out[1] = sqrt(d);
+    }
+}
+
+// tail: 1 = the launch has one workgroup more than the pass needs; it runs continuity_tail (2: slab_seal_tail)
 // WALK: the large-channel form of the walk (see the "_w" kernels): entries ahead, fluid / wall loops, fold hoisted
 // (bid, nb: this workgroup's index among the nb workgroups of the pass; c_*: the LDS tile arrays of the calling kernel)
 template <int LPP, bool WALK, int TILE>
@@ -1609,6 +1668,13 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const int tid = blk * kBlock + threadIdx.x;
     const int i = tid / LPP, sub = tid % LPP;
     const bool in_cap = i < t.cap;
+    if (WALK && beyond_population<LPP>(clk, blk)) {  // nothing here: only the workgroup's entry of the max |v|^2 reduction is owed
+        if (threadIdx.x == 0 && clk->run[q] && !next_half) {
+            if (tail) __hip_atomic_store(reinterpret_cast<unsigned long long *>(&t.vpart[blk]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else t.vpart[blk] = 0.0;
+        }
+        return;
+    }
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? t.veln[i] : make_double2(0.0, 0.0);
     const int packed = t.nl_cnt[tid];
@@ -1744,9 +1810,10 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
     __shared__ double c_vol[kSlots];
-    const int nb = (int)gridDim.x - tail;
+    const int nb = (int)gridDim.x - (tail ? 1 : 0);
     if (tail && (int)blockIdx.x == nb) {
-        continuity_tail(clk, q, ph, t, nb);
+        if (tail == 2) slab_seal_tail(clk, q, t, nb);
+        else continuity_tail(clk, q, ph, t, nb);
         return;
     }
     continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol, next_half);
@@ -2398,9 +2465,11 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack(const Clock *clk, int q,
 // device decides, from ALL-REDUCED max |v| and max drift, so every rank takes the same decision without the host.  In
 // between the layout is frozen: each rank sends the new state of a fixed list of boundary particles (send_idx) and the
 // receiver writes it into fixed slots (recv_slot); the lists are rebuilt with the layout.  Per step:
-//   passes A..E -> k_slab_seal2 -> [max all-reduce of {max|v|, max drift}] -> k_slab_decide -> k_slab_pack2
-//   -> [to both ring neighbours: message A, and message B = the ids of the send lists made in the PREVIOUS step]
-//   -> k_slab_recvslots (new ids only) -> k_slab_unpack2 -> {re-binning chain, k_slab_sendlist: only when the clock says so}
+//   passes A..E (the local maxima come out of pass E's tail workgroup, slab_seal_tail) -> [max all-reduce of {max|v|, max drift}]
+//   -> k_slab_pack3 (decision, message A, clock) -> [to both ring neighbours: message A, and message B = the ids of the send
+//   lists made in the PREVIOUS step] -> k_slab_unpack3 (new ids -> slots; message A) -> {re-binning chain, k_slab_sendlist:
+//   only when the clock says so}
+// (round 3: ten launches of this sequence folded into three -- "last workgroup out" epilogues instead of one-thread kernels)
 // Ownership goes by the binned column (Grid::own_by_cell).  A particle that crosses a slab boundary changes owner at
 // the next re-binning: both ranks hold it (the old owner keeps everything in its window), the new owner names it in
 // its id list and the old owner finds its copy through slot_of_id.
@@ -2414,132 +2483,219 @@ struct SlabLists {
     int *ids_send[2];   // message B, outgoing: [1 + msg_cap] count, ids (device buffers owned by the context)
 };
 
-// local max |v| and max drift of the owned particles -> out[0..1] (input of the all-reduce); single workgroup
-__global__ __launch_bounds__(kScanBlock) void k_slab_seal2(const Clock *clk, int q, int n_vpart, const double *vpart,
-                                                           const double *dpart, double *out)
+// "Last workgroup out": every workgroup of a kernel takes a ticket when its work is done; the one that draws the last
+// ticket sees the complete result of all the others (counters are read with agent-scope atomics) and finishes the
+// kernel's single-thread epilogue -- what used to be a one-thread kernel of its own behind it.  Returns true in every
+// thread of that workgroup; the ticket counter is back at zero for the next kernel that uses it.  Atomics on one
+// address are served at ~20 ns apiece: kernels that end this way run on a few hundred workgroups at most (grid-stride).
+__device__ __forceinline__ bool last_workgroup_out(int *ticket, int n_workgroups)  // n_workgroups: how many draw a ticket
 {
-    if (!clk->run[q]) { if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; } return; }
-    double m = 0.0, d = 0.0;
-    for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) { m = fmax(m, vpart[k]); d = fmax(d, dpart[k]); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); d = fmax(d, __shfl_xor(d, off)); }
-    __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; }
+    // No agent-scope fence here: on this chip a release fence writes the XCD's whole L2 back, once per workgroup (measured:
+    // a 0.76 M-particle slab step 380 -> 510 us).  What the epilogue reads of the other workgroups' work are counters
+    // kept by RETURNING atomics (performed at the coherence point before their wave went on) and relaxed agent-scope
+    // stores by the ticket-drawing thread itself, which the s_waitcnt below has seen acknowledged.
+    __shared__ int s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
-        out[0] = sqrt(m);
-        out[1] = sqrt(d);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int drawn = atomicAdd(ticket, 1);
+        s_last = drawn == n_workgroups - 1 ? 1 : 0;
+        if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    return s_last != 0;
+}
+__device__ __forceinline__ int peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one slot of a shared counter per accepted lane, one atomic per wavefront (750 k single atomics on one address were
+// 200 us of every re-binning step of a 0.76 M-particle slab)
+__device__ __forceinline__ int wave_take_slot(int *counter, bool take)
+{
+    const unsigned long long m = __ballot(take);
+    if (!m) return 0;
+    const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == lead) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, lead);
+    return base + __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
 }
 
-// one thread: advance the clock with the global maxima and decide whether this step ends with a re-binning
-__global__ void k_slab_decide(Clock *clk, int q, Phys ph, const double *vd_global, const int *flags, double half_skin, int K)
+// Global maxima known (vd_global = all-reduced {max |v|, max drift}): decide whether this step ends with a re-binning,
+// write message A, advance the clock.  Every workgroup takes the decision by itself from the OLD clock -- the clock is
+// only advanced by the last workgroup out, when nobody reads the old one any more.
+//   frozen step    : the new state of the send-list particles, in list order;
+//   re-binning step: every owned particle's new state goes to `keep` (it stays in this window) and, near a boundary,
+//                    to the neighbour -- as in k_slab_pack.
+// sn = the NEW state (S[1-q]); layout arrays (mass, id, cell) are those of the step.
+__global__ __launch_bounds__(kBlock) void k_slab_pack3(Clock *clk, int q, Grid g, Phys ph, FluidSet sn, SlabPack p, SlabLists L,
+                                                       const double *vd_global, int *flags, double half_skin, int K, int *ticket)
 {
-    if (!clk->run[q]) { clk->run[1 - q] = 0; return; }
+    const bool run = clk->run[q] != 0;
+    if (!run) {  // a stopped loop keeps the following slots idle and sends -1
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            clk->run[1 - q] = 0;
+            p.send_l[0] = -1.0;
+            p.send_r[0] = -1.0;
+        }
+        return;
+    }
+    const double drift = vd_global[1];
+    const bool rb = !(drift <= half_skin) || clk->pos_count >= K - 1;  // = clock_step's decision (dyn_K = K)
+    const int stride = (int)gridDim.x * kBlock;
+    int n_ticket = (int)gridDim.x;
+    if (!rb) {
+        n_ticket = min(n_ticket, (2 * p.msg_cap + kBlock - 1) / kBlock);
+        if ((int)blockIdx.x >= n_ticket) return;  // nothing to do and nothing to wait for
+        for (int e = blockIdx.x * kBlock + threadIdx.x; e < 2 * p.msg_cap; e += stride) {
+            const int side = e < p.msg_cap ? 0 : 1, sl = e - side * p.msg_cap;
+            if (sl >= L.send_cnt[side]) continue;
+            const int k = L.send_idx[side][sl];
+            const double2 pn = sn.pos[k], vn = sn.vel[k];
+            msg_put(side ? p.send_r : p.send_l, p.msg_cap, sl, pn.x + (side ? p.shift_r : p.shift_l), pn.y, vn.x, vn.y,
+                    sn.drho[k], 0.0, 0);
+        }
+    } else {
+        // Every workgroup takes one contiguous chunk of the slots.  The kept particles of a chunk get consecutive places
+        // in the keep arrays: count them, reserve the range with ONE atomic per workgroup, then hand the places out with a
+        // block scan per sweep (a place per wavefront and sweep meant 12 k returning atomics on one address, ~13 ns each:
+        // 150 us of every re-binning step of a 0.76 M-particle slab; the few boundary particles keep theirs).
+        __shared__ int s_wave[kBlock / 64 + 1];
+        __shared__ int s_base;
+        const int n = clk->n;
+        const int chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + kBlock - 1) / kBlock * kBlock;
+        const int lo = min(n, (int)blockIdx.x * chunk), hi = min(n, lo + chunk);
+        auto kept = [&](int i) {
+            if (i >= hi || !owns(g, 0.0, sn.cell[i])) return false;  // (halo copies: their owner sends fresh ones)
+            const double x = sn.pos[i].x;
+            return x >= p.win_lo && x < p.win_hi;
+        };
+        int mine_cnt = 0;
+        for (int i = lo + (int)threadIdx.x; i < hi; i += kBlock) mine_cnt += kept(i) ? 1 : 0;
+        int total;
+        (void)block_exclusive_scan_t<kBlock>(mine_cnt, total, s_wave);
+        if (threadIdx.x == 0) s_base = total > 0 ? atomicAdd(&p.counters[0], total) : 0;
+        __syncthreads();
+        int place = s_base;
+        for (int base = lo; base < hi; base += kBlock) {  // (uniform trip count per workgroup)
+            const int i = base + (int)threadIdx.x;
+            const bool mine = i < hi && owns(g, 0.0, sn.cell[i]);
+            double2 pn = make_double2(0.0, 0.0), vn = pn;
+            double dr = 0.0, m = 0.0;
+            int id = 0;
+            if (mine) { pn = sn.pos[i]; vn = sn.vel[i]; dr = sn.drho[i]; m = sn.mass[i]; id = sn.id[i]; }
+            const double xn = pn.x, yn = pn.y;
+            const bool keep = mine && xn >= p.win_lo && xn < p.win_hi;
+            const bool to_l = mine && xn < g.own_lo + p.halo_w, to_r = mine && xn >= g.own_hi - p.halo_w;
+            int sweep_total;
+            const int kk = place + block_exclusive_scan_t<kBlock>(keep ? 1 : 0, sweep_total, s_wave);
+            place += sweep_total;
+            const int kl = wave_take_slot(&p.counters[1], to_l);
+            const int kr = wave_take_slot(&p.counters[2], to_r);
+            if (keep) {
+                if (kk < p.keep_cap) {
+                    p.kpos[kk] = pn; p.kvel[kk] = vn; p.kdrho[kk] = dr; p.kmass[kk] = m; p.kid[kk] = id;
+                    int cx, cy;
+                    cell_of(g, xn, yn, cx, cy);
+                    const int c = cx * g.ncy + cy;
+                    p.cellid[kk] = c;
+                    atomicAdd(&p.count[c], 1);
+                } else atomicOr(flags, 2);
+            }
+            if (to_l) {
+                if (kl < p.msg_cap) msg_put(p.send_l, p.msg_cap, kl, xn + p.shift_l, yn, vn.x, vn.y, dr, m, id);
+                else atomicOr(flags, 2);
+            }
+            if (to_r) {
+                if (kr < p.msg_cap) msg_put(p.send_r, p.msg_cap, kr, xn + p.shift_r, yn, vn.x, vn.y, dr, m, id);
+                else atomicOr(flags, 2);
+            }
+        }
+    }
+    if (!last_workgroup_out(ticket, n_ticket) || threadIdx.x != 0) return;
+    p.send_l[0] = (double)(rb ? min(peek(&p.counters[1]), p.msg_cap) : L.send_cnt[0]);
+    p.send_r[0] = (double)(rb ? min(peek(&p.counters[2]), p.msg_cap) : L.send_cnt[1]);
     const Clock c0 = *clk;
-    clock_step(clk, c0, q, ph, vd_global[0], *flags, -1, vd_global[1], 0, half_skin, K);
+    clock_step(clk, c0, q, ph, vd_global[0], peek(flags), -1, drift, 0, half_skin, K);
     if (clk->rebuild_now) clk->rebuild_now = 1;  // (no histogram is taken ahead of time in a slab)
 }
 
-// message A.  Frozen step: the new state of the send-list particles, in list order.  Re-binning step: every owned
-// particle's new state goes to `keep` (it stays in this window) and, near a boundary, to the neighbour -- as in
-// k_slab_pack.  sn = the NEW state (S[1-q]); layout arrays (mass, id, cell) are those of the step.
-__global__ __launch_bounds__(kBlock) void k_slab_pack2(const Clock *clk, int q, Grid g, FluidSet sn, SlabPack p, SlabLists L,
-                                                       int *flags)
+// Message A arrived, and with it message B: the ids of the send lists the neighbours made in the PREVIOUS step (header
+// -1: the lists of the cycle stay).  New ids are resolved to slots first (where do the particles the neighbours will
+// keep sending live here?) -- not tied to the step slot being active: the slot after the loop's last step still
+// delivers the ids that step made.  Then message A.  Frozen step: scatter the entries into their slots of the new
+// state.  Re-binning step: append them behind the kept particles and bin them (k_slab_unpack); the last workgroup out
+// then opens the new layout (particle count, counters back to zero).
+__global__ __launch_bounds__(kBlock) void k_slab_unpack3(Clock *clk, int q, Grid g, FluidSet sn, SlabPack p, SlabLists L,
+                                                         const double *recv_l, const double *recv_r, const int *ids_l,
+                                                         const int *ids_r, int *n_new, int *flags, int *ticket)
 {
-    if (!clk->run[q]) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (!clk->rebuild_now) {
-        if (i >= 2 * p.msg_cap) return;
-        const int side = i < p.msg_cap ? 0 : 1, sl = i - side * p.msg_cap;
-        if (sl >= L.send_cnt[side]) return;
-        const int k = L.send_idx[side][sl];
-        const double2 pn = sn.pos[k], vn = sn.vel[k];
-        msg_put(side ? p.send_r : p.send_l, p.msg_cap, sl, pn.x + (side ? p.shift_r : p.shift_l), pn.y, vn.x, vn.y, sn.drho[k],
-                0.0, 0);
-        return;
-    }
-    if (i >= clk->n) return;
-    if (!owns(g, 0.0, sn.cell[i])) return;  // halo copy: its owner sends a fresh one
-    const double2 pn = sn.pos[i], vn = sn.vel[i];
-    const double xn = pn.x, yn = pn.y, dr = sn.drho[i], m = sn.mass[i];
-    const int id = sn.id[i];
-    if (xn >= p.win_lo && xn < p.win_hi) {
-        const int k = atomicAdd(&p.counters[0], 1);
-        if (k < p.keep_cap) {
-            p.kpos[k] = pn; p.kvel[k] = vn; p.kdrho[k] = dr; p.kmass[k] = m; p.kid[k] = id;
-            int cx, cy;
-            cell_of(g, xn, yn, cx, cy);
-            const int c = cx * g.ncy + cy;
-            p.cellid[k] = c;
-            atomicAdd(&p.count[c], 1);
-        } else atomicOr(flags, 2);
-    }
-    if (xn < g.own_lo + p.halo_w) {
-        const int k = atomicAdd(&p.counters[1], 1);
-        if (k < p.msg_cap) msg_put(p.send_l, p.msg_cap, k, xn + p.shift_l, yn, vn.x, vn.y, dr, m, id);
-        else atomicOr(flags, 2);
-    }
-    if (xn >= g.own_hi - p.halo_w) {
-        const int k = atomicAdd(&p.counters[2], 1);
-        if (k < p.msg_cap) msg_put(p.send_r, p.msg_cap, k, xn + p.shift_r, yn, vn.x, vn.y, dr, m, id);
-        else atomicOr(flags, 2);
-    }
-}
-
-// one thread: the message counts (a stopped loop sends -1)
-__global__ void k_slab_seal_msg(const Clock *clk, int q, SlabPack p, SlabLists L)
-{
-    const bool run = clk->run[q] != 0;
-    const bool rb = clk->rebuild_now != 0;
-    p.send_l[0] = !run ? -1.0 : (double)(rb ? min(p.counters[1], p.msg_cap) : L.send_cnt[0]);
-    p.send_r[0] = !run ? -1.0 : (double)(rb ? min(p.counters[2], p.msg_cap) : L.send_cnt[1]);
-}
-
-// message A, receiving side.  Frozen step: scatter the entries into their slots of the new state.  Re-binning step:
-// append them behind the kept particles and bin them (k_slab_unpack).
-__global__ __launch_bounds__(kBlock) void k_slab_unpack2(const Clock *clk, int q, Grid g, FluidSet sn, SlabPack p, SlabLists L,
-                                                         const double *recv_l, const double *recv_r, int *n_new, int *flags)
-{
-    if (!clk->run[q]) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int nl = (int)recv_l[0], nr = (int)recv_r[0];
     const int cap = p.msg_cap;
-    if (!clk->rebuild_now) {
-        if (i == 0 && (nl != L.recv_cnt[0] || nr != L.recv_cnt[1])) atomicOr(flags, 2);  // the neighbours disagree with my lists
-        if (i >= 2 * cap) return;
-        const int side = i < cap ? 0 : 1, sl = i - side * cap;
-        if (sl >= L.recv_cnt[side]) return;
-        const double *b = (side ? recv_r : recv_l) + 1;
-        const int k = L.recv_slot[side][sl];
-        sn.pos[k] = make_double2(b[sl], b[(size_t)cap + sl]);
-        sn.vel[k] = make_double2(b[2 * (size_t)cap + sl], b[3 * (size_t)cap + sl]);
-        sn.drho[k] = b[4 * (size_t)cap + sl];
-        return;
+    const bool run = clk->run[q] != 0, rb = clk->rebuild_now != 0;
+    const int n_now = clk->n;
+    const int side = i < cap ? 0 : 1, sl = i - side * cap;
+    int slot = -1, n_list = 0;
+    if (i < 2 * cap) {
+        const int *ids = side ? ids_r : ids_l;
+        const int cnt = ids[0];
+        if (cnt >= 0) {  // new lists
+            n_list = min(cnt, cap);
+            if (sl == 0) {
+                if (cnt > cap) atomicOr(flags, 2);
+                L.recv_cnt[side] = n_list;
+            }
+            if (sl < n_list) {
+                const int id = ids[1 + sl];
+                const int k = L.slot_of_id[id];
+                if (k < 0 || k >= n_now || sn.id[k] != id) atomicOr(flags, 2);  // I do not hold that particle
+                else { L.recv_slot[side][sl] = k; slot = k; }
+            }
+        } else {
+            n_list = L.recv_cnt[side];
+            if (sl < n_list) slot = L.recv_slot[side][sl];
+        }
     }
-    const int nk = min(p.counters[0], p.keep_cap);
-    if (nl < 0 || nr < 0 || nk + nl + nr > p.keep_cap) {
-        if (i == 0) { atomicOr(flags, 2); *n_new = min(nk, p.keep_cap); }
-        return;
+    if (run && !rb) {
+        if (i < 2 * cap) {
+            const double *msg = side ? recv_r : recv_l;
+            if (sl == 0 && (int)msg[0] != n_list) atomicOr(flags, 2);  // the neighbour disagrees with my lists
+            if (slot >= 0) {
+                const double *b = msg + 1;
+                sn.pos[slot] = make_double2(b[sl], b[(size_t)cap + sl]);
+                sn.vel[slot] = make_double2(b[2 * (size_t)cap + sl], b[3 * (size_t)cap + sl]);
+                sn.drho[slot] = b[4 * (size_t)cap + sl];
+            }
+        }
+    } else if (run) {
+        const int nl = (int)recv_l[0], nr = (int)recv_r[0];
+        const int nk = min(peek(&p.counters[0]), p.keep_cap);
+        if (nl < 0 || nr < 0 || nk + nl + nr > p.keep_cap) {
+            if (i == 0) { atomicOr(flags, 2); __hip_atomic_store(n_new, min(nk, p.keep_cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        } else {
+            if (i == 0) __hip_atomic_store(n_new, nk + nl + nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < nl + nr) {
+                const double *b = (i < nl ? recv_l : recv_r) + 1;
+                const int s2 = i < nl ? i : i - nl;
+                const int d = nk + i;
+                const double x = b[s2], y = b[(size_t)cap + s2];
+                p.kpos[d] = make_double2(x, y);
+                int cx, cy;
+                cell_of(g, x, y, cx, cy);
+                const int c = cx * g.ncy + cy;
+                p.cellid[d] = c;
+                atomicAdd(&p.count[c], 1);
+                p.kvel[d] = make_double2(b[2 * (size_t)cap + s2], b[3 * (size_t)cap + s2]);
+                p.kdrho[d] = b[4 * (size_t)cap + s2];
+                p.kmass[d] = b[5 * (size_t)cap + s2];
+                p.kid[d] = (int)b[6 * (size_t)cap + s2];
+            }
+        }
     }
-    if (i == 0) *n_new = nk + nl + nr;
-    if (i < nl + nr) {
-        const double *b = (i < nl ? recv_l : recv_r) + 1;
-        const int sl = i < nl ? i : i - nl;
-        const int d = nk + i;
-        const double x = b[sl], y = b[(size_t)cap + sl];
-        p.kpos[d] = make_double2(x, y);
-        int cx, cy;
-        cell_of(g, x, y, cx, cy);
-        const int c = cx * g.ncy + cy;
-        p.cellid[d] = c;
-        atomicAdd(&p.count[c], 1);
-        p.kvel[d] = make_double2(b[2 * (size_t)cap + sl], b[3 * (size_t)cap + sl]);
-        p.kdrho[d] = b[4 * (size_t)cap + sl];
-        p.kmass[d] = b[5 * (size_t)cap + sl];
-        p.kid[d] = (int)b[6 * (size_t)cap + sl];
-    }
+    if (!(run && rb)) return;  // (uniform over the grid: nobody takes a ticket)
+    if (!last_workgroup_out(ticket, (int)gridDim.x) || threadIdx.x != 0) return;
+    clk->n = peek(n_new);  // from here on the re-binning chain works on the new particle count
+    p.counters[0] = 0; p.counters[1] = 0; p.counters[2] = 0;
+    L.send_cnt[0] = 0; L.send_cnt[1] = 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_slot_of_id(int n, const int *id, int *slot_of_id)
@@ -2548,46 +2704,38 @@ __global__ __launch_bounds__(kBlock) void k_slot_of_id(int n, const int *id, int
     if (i < n) slot_of_id[id[i]] = i;
 }
 
-// one thread, re-binning steps: the particle count of the new layout, counters back to zero
-__global__ void k_slab_begin_rebin(Clock *clk, int q, const int *n_new, int *pack_counters, int *send_cnt)
-{
-    if (!clk->run[q] || !clk->rebuild_now) return;
-    clk->n = *n_new;
-    pack_counters[0] = 0; pack_counters[1] = 0; pack_counters[2] = 0;
-    send_cnt[0] = 0; send_cnt[1] = 0;
-}
-
 // re-binning steps, on the NEW layout: owned particles within halo_w of a boundary form the send lists of the cycle;
-// their ids are message B
+// their ids are message B, whose header the last workgroup out writes (-1: the lists of the cycle stay)
 __global__ __launch_bounds__(kBlock) void k_slab_sendlist(const Clock *clk, int q, Grid g, FluidSet sn, SlabPack p, SlabLists L,
-                                                          int *flags, int force)
+                                                          int *flags, int force, int *ticket)
 {
-    if (!force && (!clk->run[q] || !clk->rebuild_now)) return;  // force: the lists of the first cycle
+    const bool rb = force || (clk->run[q] && clk->rebuild_now);  // force: the lists of the first cycle
+    if (!rb) {  // (uniform over the grid)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { L.ids_send[0][0] = -1; L.ids_send[1][0] = -1; }
+        return;
+    }
     const int n = clk->n;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        if (!owns(g, 0.0, sn.cell[i])) continue;
-        const double x = sn.pos[i].x;
+    for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {  // (uniform trip count per workgroup)
+        const int i = base + (int)threadIdx.x;
+        const bool mine = i < n && owns(g, 0.0, sn.cell[i]);
+        const double x = mine ? sn.pos[i].x : 0.0;
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
-            const bool near = side ? x >= g.own_hi - p.halo_w : x < g.own_lo + p.halo_w;
+            const bool near = mine && (side ? x >= g.own_hi - p.halo_w : x < g.own_lo + p.halo_w);
+            const int k = wave_take_slot(&L.send_cnt[side], near);
             if (!near) continue;
-            const int k = atomicAdd(&L.send_cnt[side], 1);
             if (k < p.msg_cap) {
                 L.send_idx[side][k] = i;
                 L.ids_send[side][1 + k] = sn.id[i];
             } else atomicOr(flags, 2);
         }
     }
-}
-
-// one thread: header of message B (-1: the lists of the cycle stay)
-__global__ void k_slab_seal_ids(const Clock *clk, int q, SlabPack p, SlabLists L, int force)
-{
-    const bool rb = force || (clk->run[q] && clk->rebuild_now);
+    if (!last_workgroup_out(ticket, (int)gridDim.x) || threadIdx.x != 0) return;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
-        if (rb) L.send_cnt[side] = min(L.send_cnt[side], p.msg_cap);
-        L.ids_send[side][0] = rb ? L.send_cnt[side] : -1;
+        const int cnt = min(peek(&L.send_cnt[side]), p.msg_cap);
+        L.send_cnt[side] = cnt;
+        L.ids_send[side][0] = cnt;
     }
 }
 

@@ -140,7 +140,7 @@ struct sphx_ctx {
     int col0 = 0, col1 = 0;  // owned global columns [col0, col1)
     DevBuf<double2> kpos, kvel;
     DevBuf<double> kdrho, kmass;
-    DevBuf<int> kid, counters, n_new;
+    DevBuf<int> kid, counters, n_new, ticket;  // (ticket: see last_workgroup_out)
     SlabPack pack{};
     int64_t slab_steps_enqueued = 0, slab_step0 = 0;
     // optional (SPHX_SLAB_GRAPH=1): each half-step captured once per parity (and per buffer set) and replayed;
@@ -153,6 +153,13 @@ struct sphx_ctx {
     bool lists_ready = false;
     ncclComm_t comm = nullptr;
     hipEvent_t ev_computed = nullptr, ev_received = nullptr;  // single-process ring: cross-stream ordering
+    // Whole slab steps as ONE replayable graph (sphx_slab_graph_prepare): kSlabGraphSteps steps of the native loop -- kernels,
+    // the RCCL calls (sphx_slab_run) or the device-to-device copies and cross-stream dependencies of an in-process ring
+    // (sphx_slab_group_run; held by slab 0) -- captured once the loop has run eagerly at least twice
+    hipGraphExec_t steps_graph = nullptr;
+    std::vector<const sphx_ctx *> steps_graph_ring;  // the contexts the graph was captured for
+    int steps_graph_cur = 0;                          // ... and the state parity it starts from
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
     const void *slab_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
@@ -200,6 +207,9 @@ struct sphx_ctx {
         if (stream) (void)hipStreamSynchronize(stream);  // the buffers go back to the pool: nothing may still use them
         drop_graph();
         for (auto &h : slab_graph) for (auto &e : h) if (e) (void)hipGraphExecDestroy(e);
+        if (steps_graph) (void)hipGraphExecDestroy(steps_graph);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         timer.collect();
         timer.drop_graph_events();
         if (ev_computed) (void)hipEventDestroy(ev_computed);
@@ -265,7 +275,6 @@ ReorderArgs reorder_args(const double2 *pos, const double2 *vel, const double *d
 int dual_rate_substeps(const sphx_params &prm)
 {
     if (prm.dual_rate <= 1) return 1;
-    require(prm.dual_rate <= 4, "SPHX:Ctx:dual_rate", "dual_rate must be 0, 1 or 2..4 (inner sub-steps per outer step)");
     const double h = prm.h;
     const double dt_ac = 0.25 * h / (1.1 * prm.c_f);  // at max|v| = 0.1 c_f, where the reference's set-up runs
     const double dt_visc = 0.125 * h * h * prm.rho0 / std::max(prm.mu, 1e-12);
@@ -312,7 +321,7 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
     // large channels (few lanes per particle) run the "_w" forms of passes B, CD and E, see sphx_kernels.hpp
     bool walk = false;
     if constexpr (LPP <= 8) walk = c->walk_kernels;
-    const dim3 ge(c->n_blocks_particles + tail);
+    const dim3 ge(c->n_blocks_particles + (tail ? 1 : 0));  // tail: 1 = clock, 2 = a slab's local maxima (slab_seal_tail)
     const char *name_e = tail ? "k_continuity_clock" : "k_continuity";
     if (!walk) {
         if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
@@ -580,7 +589,10 @@ sphx_ctx::CachedGraph &get_graph(sphx_ctx *c, int cur, int lay, int pos, int n)
     const std::array<int, 4> key{cur, c->dyn ? 0 : lay, c->dyn ? 0 : pos, n};
     auto it = c->graphs.find(key);
     if (it != c->graphs.end()) return it->second;
-    if (c->graphs.size() >= kMaxGraphs) c->drop_graph();
+    if (c->graphs.size() >= kMaxGraphs) {
+        SPHX_HIP(hipStreamSynchronize(c->stream));  // earlier batches may still be replaying the graphs about to be destroyed
+        c->drop_graph();
+    }
     const int K = c->rebuild_every;
     const bool prof = c->profiling;
     c->profiling = false;
@@ -856,7 +868,9 @@ void ctx_alloc(sphx_ctx *c, int cap)
     // Small channels with a skin: move steps are 4 launches, the clock update rides in pass E (continuity_tail);
     // vpart entries then double as "ready" flags and start out empty (all ones)
     c->tail_clock = c->skin > 0.0 && !c->is_slab && !c->dyn && c->n_vpart <= 2048 && !std::getenv("SPHX_NO_TAIL_CLOCK");
-    SPHX_HIP(hipMemsetAsync(c->vpart.get(), c->tail_clock ? 0xFF : 0, (size_t)c->n_vpart * sizeof(double), c->stream));
+    // (skinned slabs: the same hand-over feeds slab_seal_tail)
+    const bool vpart_flags = c->tail_clock || (c->is_slab && c->rebuild_every > 1);
+    SPHX_HIP(hipMemsetAsync(c->vpart.get(), vpart_flags ? 0xFF : 0, (size_t)c->n_vpart * sizeof(double), c->stream));
     c->dpart.alloc(c->n_vpart);
     c->dpart.zero(c->stream);
     c->n_vtiles = (!c->is_slab && c->n_vpart > 4 * kMaxTile) ? (int)div_up((size_t)c->n_vpart, kMaxTile) : 0;
@@ -884,7 +898,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get()};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), nullptr};
     // E|A fusion: small static-schedule channels on the compact kernels (the clock rides in the tail workgroup)
     c->fuse_ea = c->tail_clock && (c->lpp >= 16 || (c->walk_kernels && !c->lds_tiles_be && c->lpp >= 2)) && !std::getenv("SPHX_NO_FUSE_EA");
     c->tmp_par[0] = c->tmp;
@@ -991,6 +1005,8 @@ void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
 void common_checks(const sphx_params *prm, int n_fluid, int n_total)
 {
     require(prm != nullptr, "SPHX:Ctx:params", "params must not be NULL");
+    require(prm->dual_rate >= 0 && prm->dual_rate <= 4, "SPHX:Ctx:dual_rate",
+            "dual_rate must be 0, 1 or 2..4 (inner sub-steps per outer step)");
     require(n_total > 0 && n_fluid > 0 && n_fluid <= n_total, "SPH:Neighbor:count",
             "Invalid n_fluid/n_total or inconsistent pos size.");
     require(prm->h > 0.0 && prm->DL > 0.0, "SPH:Neighbor:param", "h and DL must be positive.");
@@ -1049,7 +1065,11 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // 79.5 / 72.1 / 72.6 / 74.8 at 130 k, 142 / 118 / 119 / 121 at 250 k (K = 5: its thin skin forces rebuilds + cool-downs) -> 8;
     // 0.5 M: 189 / 192 at K = 5 / 8, 6 M: 2 201 / 2 262 -> 5.
     int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 16 : (nf <= 300000 ? 8 : 5));
-    const int n_sub = (c->lpp >= 16 && !c->is_slab) ? dual_rate_substeps(*prm) : 1;  // dual-rate loop: a slot moves particles n_sub times as far
+    // dual-rate loop: a slot moves particles n_sub times as far.  Same eligibility as ctx_alloc's n_in (the fused E|A launch
+    // with the clock in its tail workgroup: a skin, static schedule, <= 2048 workgroups, compact kernels)
+    const bool dual_ok = c->lpp >= 16 && !c->is_slab && K > 1 && prm->dynamic_rebin != 1 &&
+                         div_up((size_t)nf * c->lpp, kBlock) <= 2048 && !std::getenv("SPHX_NO_TAIL_CLOCK") && !std::getenv("SPHX_NO_FUSE_EA");
+    const int n_sub = dual_ok ? dual_rate_substeps(*prm) : 1;
     if (n_sub > 1 && prm->rebuild_every <= 0) K = std::max(2, K / n_sub);
     const double d_step = 0.035 * prm->h * n_sub;
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
@@ -1125,11 +1145,14 @@ void emit_pairs(sphx_ctx *c, bool fill)
     c->pl_valid = true;
 }
 
+// time one step slot advances by, before clipping to the target (dual-rate loop: n_in sub-steps, see next_dt)
 double host_dt_unclipped(const sphx_ctx *c, double vmax)
 {
     const double hh = c->phys.kc.h;
-    return std::min(std::min(0.25 * hh / std::max(c->phys.c_f + vmax, 1e-12), 0.125 * hh * hh / std::max(c->phys.nu, 1e-12)),
-                    0.25 * std::sqrt(hh / std::max(std::fabs(c->phys.g), 1e-12)));
+    const double dt_ac = 0.25 * hh / std::max(c->phys.c_f + vmax, 1e-12);
+    const double dt_rest = std::min(0.125 * hh * hh / std::max(c->phys.nu, 1e-12),
+                                    0.25 * std::sqrt(hh / std::max(std::fabs(c->phys.g), 1e-12)));
+    return std::min(c->n_in * dt_ac, dt_rest);
 }
 
 void throw_on_status(const sphx_ctx *c)
@@ -1685,8 +1708,8 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     upload_walls(c, nw_local, hw.x.data(), hw.y.data(), hw.mass.data(), wvx.data(), wvy.data(), hw.id.data(), false);
 
     c->kpos.alloc(cap); c->kvel.alloc(cap); c->kdrho.alloc(cap); c->kmass.alloc(cap);
-    c->kid.alloc(cap); c->counters.alloc(3); c->n_new.alloc(1);
-    c->counters.zero(c->stream);
+    c->kid.alloc(cap); c->counters.alloc(3); c->n_new.alloc(1); c->ticket.alloc(1);
+    c->counters.zero(c->stream); c->ticket.zero(c->stream); c->n_new.zero(c->stream);
     SlabPack p{};
     p.counters = c->counters.get();
     p.kpos = c->kpos.get(); p.kvel = c->kvel.get(); p.kdrho = c->kdrho.get();
@@ -1795,6 +1818,7 @@ SPHX_EXPORT int sphx_slab_local_vmax(sphx_ctx *c, double *vmax_dev)
 {
     SPHX_TRY
     require(c != nullptr && c->is_slab && vmax_dev != nullptr, "SPHX:Slab:ctx", "not a slab context");
+    require(c->rebuild_every == 1, "SPHX:Slab:protocol", "local_vmax / prepare / compute / finish drive a slab created with rebuild_every = 1");
     const FluidSet fs = c->view(c->cur, c->cur);
     hipLaunchKernelGGL(k_vmax_init, dim3(1), dim3(kScanBlock), 0, c->stream, c->clock.get(), c->grid, (const double2 *)fs.pos,
                        (const double2 *)fs.vel, vmax_dev);
@@ -1808,6 +1832,7 @@ SPHX_EXPORT int sphx_slab_prepare(sphx_ctx *c, double t_target, int64_t max_step
 {
     SPHX_TRY
     require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    require(c->rebuild_every == 1, "SPHX:Slab:protocol", "local_vmax / prepare / compute / finish drive a slab created with rebuild_every = 1");
     arm_clock(c, t_target, (long long)max_steps, c->cur, vmax_global_dev);
     SPHX_HIP(hipGetLastError());
     return SPHX_OK;
@@ -1892,6 +1917,7 @@ SPHX_EXPORT int sphx_slab_finish(sphx_ctx *c, const double *recv_left_dev, const
     SPHX_TRY
     require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
     require(recv_left_dev && recv_right_dev && vmax_global_dev, "SPHX:Slab:buffers", "message / vmax buffers must not be NULL");
+    require(c->rebuild_every == 1, "SPHX:Slab:protocol", "compute/finish drive a slab created with rebuild_every = 1");
     slab_finish_impl(c, recv_left_dev, recv_right_dev, vmax_global_dev);
     return SPHX_OK;
     SPHX_CATCH
@@ -1924,26 +1950,37 @@ struct Rccl {
     static Rccl &get()
     {
         static Rccl r;
-        if (r.lib) return r;
+        static bool ready = false;
+        if (ready) return r;
+        // resolve into a local table and publish it only when every entry point is there: a failed attempt leaves nothing
+        // half-initialised behind (an older librccl lacking a symbol must fail every call, not only the first)
+        Rccl t;
+        std::string why;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+            t.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (t.lib) break;
+            if (const char *e = dlerror()) why = e;
         }
-        if (!r.lib) throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", std::string("cannot load librccl: ") + dlerror());
+        if (!t.lib) throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", "cannot load librccl: " + why);
         auto sym = [&](const char *n) {
-            void *p = dlsym(r.lib, n);
-            if (!p) throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", std::string("librccl lacks ") + n);
+            void *p = dlsym(t.lib, n);
+            if (!p) {
+                (void)dlclose(t.lib);
+                throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", std::string("librccl lacks ") + n);
+            }
             return p;
         };
-        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
-        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
-        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
-        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
-        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
-        r.Send = (decltype(r.Send))sym("ncclSend");
-        r.Recv = (decltype(r.Recv))sym("ncclRecv");
-        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
-        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        t.GetUniqueId = (decltype(t.GetUniqueId))sym("ncclGetUniqueId");
+        t.CommInitRank = (decltype(t.CommInitRank))sym("ncclCommInitRank");
+        t.CommDestroy = (decltype(t.CommDestroy))sym("ncclCommDestroy");
+        t.GroupStart = (decltype(t.GroupStart))sym("ncclGroupStart");
+        t.GroupEnd = (decltype(t.GroupEnd))sym("ncclGroupEnd");
+        t.Send = (decltype(t.Send))sym("ncclSend");
+        t.Recv = (decltype(t.Recv))sym("ncclRecv");
+        t.AllReduce = (decltype(t.AllReduce))sym("ncclAllReduce");
+        t.GetErrorString = (decltype(t.GetErrorString))sym("ncclGetErrorString");
+        r = t;
+        ready = true;
         return r;
     }
     void check(ncclResult_t e, const char *what)
@@ -1961,6 +1998,15 @@ void slab_native_buffers(sphx_ctx *c)
     for (DevBuf<double> *b : {&c->msg_sl, &c->msg_sr, &c->msg_rl, &c->msg_rr, &c->vmax_l, &c->vmax_g}) b->zero(c->stream);
 }
 
+// End a capture that went wrong and drop whatever it produced.
+void abandon_capture(hipStream_t st)
+{
+    hipGraph_t junk = nullptr;
+    (void)hipStreamEndCapture(st, &junk);
+    if (junk) (void)hipGraphDestroy(junk);
+    (void)hipGetLastError();
+}
+
 struct PtrList {
     const double *p[16];
 };
@@ -1974,6 +2020,14 @@ __global__ void k_max_of(int n, PtrList src, double *out)  // thread j: componen
 }
 
 }  // namespace
+
+SPHX_EXPORT int sphx_comm_available(void)
+{
+    SPHX_TRY
+    (void)Rccl::get();  // loads librccl and resolves every entry point the native loop uses, or says what is missing
+    return SPHX_OK;
+    SPHX_CATCH
+}
 
 SPHX_EXPORT int sphx_comm_unique_id(void *id_bytes, int capacity)
 {
@@ -1995,9 +2049,11 @@ SPHX_EXPORT int sphx_slab_comm_init(sphx_ctx *c, const void *id_bytes)
     ncclUniqueId id;
     std::memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
     Rccl &R = Rccl::get();
-    R.check(R.CommInitRank(&c->comm, c->n_ranks, id, c->rank), "ncclCommInitRank");
-    slab_native_buffers(c);
+    slab_native_buffers(c);  // (before the collective call: a rank that cannot allocate must not leave the others inside it)
     SPHX_HIP(hipStreamSynchronize(c->stream));
+    ncclComm_t comm = nullptr;
+    R.check(R.CommInitRank(&comm, c->n_ranks, id, c->rank), "ncclCommInitRank");
+    c->comm = comm;
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -2078,6 +2134,91 @@ SPHX_EXPORT int sphx_comm_selftest(void)
     SPHX_CATCH
 }
 
+// The exchange of a skinned step and the all-reduce once more, this time CAPTURED into a hipGraph and replayed twice with
+// fresh payloads on a communicator of one rank: tells whether this RCCL can be captured at all (sphx_slab_graph_prepare
+// relies on it) before a multi-rank run stakes its loop on it.
+SPHX_EXPORT int sphx_comm_selftest_graph(void)
+{
+    SPHX_TRY
+    ensure_device();
+    Rccl &R = Rccl::get();
+    ncclUniqueId id;
+    R.check(R.GetUniqueId(&id), "ncclGetUniqueId");
+    ncclComm_t comm = nullptr;
+    R.check(R.CommInitRank(&comm, 1, id, 0), "ncclCommInitRank");
+    hipStream_t st = nullptr;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const size_t n = 1000;
+    DevBuf<double> sl(n), sr(n), rl(n), rr(n), v(2), vg(2);
+    DevBuf<int> il(n), ir(n), jl(n), jr(n);
+    std::vector<double> hl(n), hr(n), got_l(n), got_r(n);
+    std::vector<int> kl(n), kr(n), gi_l(n), gi_r(n);
+    bool ok = true;
+    auto exchange = [&]() {
+        R.check(R.AllReduce(v.get(), vg.get(), 2, ncclDouble, ncclMax, comm, st), "ncclAllReduce");
+        R.check(R.GroupStart(), "ncclGroupStart");
+        R.check(R.Send(sl.get(), n, ncclDouble, 0, comm, st), "ncclSend");
+        R.check(R.Send(sr.get(), n, ncclDouble, 0, comm, st), "ncclSend");
+        R.check(R.Send(il.get(), n, ncclInt32, 0, comm, st), "ncclSend");
+        R.check(R.Send(ir.get(), n, ncclInt32, 0, comm, st), "ncclSend");
+        R.check(R.Recv(rr.get(), n, ncclDouble, 0, comm, st), "ncclRecv");
+        R.check(R.Recv(rl.get(), n, ncclDouble, 0, comm, st), "ncclRecv");
+        R.check(R.Recv(jr.get(), n, ncclInt32, 0, comm, st), "ncclRecv");
+        R.check(R.Recv(jl.get(), n, ncclInt32, 0, comm, st), "ncclRecv");
+        R.check(R.GroupEnd(), "ncclGroupEnd");
+    };
+    try {
+        SPHX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        rl.zero(st); rr.zero(st); jl.zero(st); jr.zero(st); vg.zero(st); v.zero(st); sl.zero(st); sr.zero(st); il.zero(st); ir.zero(st);
+        exchange();  // eagerly first: channels and buffers of the communicator are set up outside the capture
+        SPHX_HIP(hipStreamSynchronize(st));
+        SPHX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        try {
+            exchange();
+            exchange();  // (two steps per graph, as the step graph holds several)
+        } catch (...) {
+            abandon_capture(st);
+            throw;
+        }
+        SPHX_HIP(hipStreamEndCapture(st, &g));
+        SPHX_HIP(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+        for (int rep = 0; rep < 2 && ok; ++rep) {
+            for (size_t k = 0; k < n; ++k) {
+                hl[k] = 1.0 + k + 1000.0 * rep; hr[k] = -2.0 - k - 1000.0 * rep;
+                kl[k] = 7 + (int)k + 100000 * rep; kr[k] = -9 - (int)k - 100000 * rep;
+            }
+            const double hv[2] = {3.25 + rep, -1.5 - rep};
+            double gv[2] = {0.0, 0.0};
+            sl.upload(hl.data(), n, st); sr.upload(hr.data(), n, st); il.upload(kl.data(), n, st); ir.upload(kr.data(), n, st);
+            v.upload(hv, 2, st);
+            rl.zero(st); rr.zero(st); jl.zero(st); jr.zero(st); vg.zero(st);
+            SPHX_HIP(hipStreamSynchronize(st));  // (the host vectors are reused)
+            SPHX_HIP(hipGraphLaunch(exec, st));
+            SPHX_HIP(hipMemcpyAsync(got_l.data(), rl.get(), n * sizeof(double), hipMemcpyDeviceToHost, st));
+            SPHX_HIP(hipMemcpyAsync(got_r.data(), rr.get(), n * sizeof(double), hipMemcpyDeviceToHost, st));
+            SPHX_HIP(hipMemcpyAsync(gi_l.data(), jl.get(), n * sizeof(int), hipMemcpyDeviceToHost, st));
+            SPHX_HIP(hipMemcpyAsync(gi_r.data(), jr.get(), n * sizeof(int), hipMemcpyDeviceToHost, st));
+            SPHX_HIP(hipMemcpyAsync(gv, vg.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            SPHX_HIP(hipStreamSynchronize(st));
+            ok = got_r == hl && got_l == hr && gi_r == kl && gi_l == kr && gv[0] == hv[0] && gv[1] == hv[1];
+        }
+    } catch (...) {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (g) (void)hipGraphDestroy(g);
+        (void)R.CommDestroy(comm);
+        if (st) (void)hipStreamDestroy(st);
+        throw;
+    }
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(g);
+    R.check(R.CommDestroy(comm), "ncclCommDestroy");
+    SPHX_HIP(hipStreamDestroy(st));
+    if (!ok) throw Error(SPHX_ERR_DEVICE, "SPHX:Slab:rccl", "RCCL graph self-test: a replayed exchange delivered the wrong data");
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
 SPHX_EXPORT int sphx_slab_comm_destroy(sphx_ctx *c)
 {
     SPHX_TRY
@@ -2097,30 +2238,28 @@ namespace {
 // ---- one step of a skinned slab, in four phases separated by the three exchanges (see SlabLists) ----
 FluidSet slab_new_state(sphx_ctx *c) { return c->view(1 - c->cur, 0); }  // S[1-q] with the (in-place) layout arrays
 
-void slab_phase1(sphx_ctx *c)  // passes A..E into S[1-q], local maxima -> vmax_l[0..1]
+constexpr int kTicketBlocks = 1024;  // largest grid of the kernels that end with last_workgroup_out (~20 ns per ticket)
+
+void slab_phase1(sphx_ctx *c)  // passes A..E into S[1-q]; the tail workgroup of pass E leaves the local maxima in vmax_l[0..1]
 {
     const int q = c->cur;
     const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
     FluidTmp t = c->tmp;
     t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
-    launch_physics_any(c, q, s, t, 0, 0, 3);
-    launch(c, "k_slab_seal2", k_slab_seal2, dim3(1), dim3(kScanBlock), (const Clock *)c->clock.get(), q, c->n_vpart,
-           (const double *)c->vpart.get(), (const double *)c->dpart.get(), c->vmax_l.get());
+    t.seal_out = c->vmax_l.get();
+    launch_physics_any(c, q, s, t, 0, 0, 3, 2);
 }
 
-void slab_phase2(sphx_ctx *c)  // global maxima known: clock + re-binning decision, message A
+void slab_phase2(sphx_ctx *c)  // global maxima known: re-binning decision, message A, clock -- one launch
 {
     const int q = c->cur;
-    Clock *clk = c->clock.get();
-    launch(c, "k_slab_decide", k_slab_decide, dim3(1), dim3(1), clk, q, c->phys, (const double *)c->vmax_g.get(),
-           (const int *)c->flags.get(), c->half_skin(), c->rebuild_every);
     SlabPack p = c->pack;
     p.send_l = c->msg_sl.get();
     p.send_r = c->msg_sr.get();
-    const unsigned nb = std::max<unsigned>(c->n_blocks_flat, div_up((size_t)2 * c->msg_cap, kBlock));
-    launch(c, "k_slab_pack2", k_slab_pack2, dim3(nb), dim3(kBlock), (const Clock *)clk, q, c->grid, slab_new_state(c), p, c->lists,
-           c->flags.get());
-    launch(c, "k_slab_seal_msg", k_slab_seal_msg, dim3(1), dim3(1), (const Clock *)clk, q, p, c->lists);
+    // grid-stride on at most one workgroup per CU: the kernel ends with a ticket per workgroup (last_workgroup_out)
+    const unsigned nb = std::min<unsigned>(kTicketBlocks, std::max<unsigned>(c->n_blocks_flat, div_up((size_t)2 * c->msg_cap, kBlock)));
+    launch(c, "k_slab_pack3", k_slab_pack3, dim3(nb), dim3(kBlock), c->clock.get(), q, c->grid, c->phys, slab_new_state(c), p,
+           c->lists, (const double *)c->vmax_g.get(), c->flags.get(), c->half_skin(), c->rebuild_every, c->ticket.get());
 }
 
 void slab_phase3(sphx_ctx *c)  // message A arrived (and with it the ids of the lists the neighbours made in the previous step):
@@ -2129,22 +2268,17 @@ void slab_phase3(sphx_ctx *c)  // message A arrived (and with it the ids of the 
     const int q = c->cur, qf = q | kOnlyIfRebuild;
     Clock *clk = c->clock.get();
     const FluidSet d = slab_new_state(c);
-    launch(c, "k_slab_recvslots", k_slab_recvslots, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock), (const Clock *)clk, q,
-           c->pack, c->lists, (const int *)c->ids_r_[0].get(), (const int *)c->ids_r_[1].get(), (const int *)d.id, c->flags.get(), 0);
-    launch(c, "k_slab_unpack2", k_slab_unpack2, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock), (const Clock *)clk, q,
-           c->grid, d, c->pack, c->lists, (const double *)c->msg_rl.get(), (const double *)c->msg_rr.get(), c->n_new.get(),
-           c->flags.get());
-    launch(c, "k_slab_begin_rebin", k_slab_begin_rebin, dim3(1), dim3(1), clk, q, (const int *)c->n_new.get(), c->counters.get(),
-           c->send_cnt.get());
+    launch(c, "k_slab_unpack3", k_slab_unpack3, dim3(div_up((size_t)2 * c->msg_cap, kBlock)), dim3(kBlock), clk, q, c->grid, d,
+           c->pack, c->lists, (const double *)c->msg_rl.get(), (const double *)c->msg_rr.get(), (const int *)c->ids_r_[0].get(),
+           (const int *)c->ids_r_[1].get(), c->n_new.get(), c->flags.get(), c->ticket.get());
     const int kRebinBlocks = 4096;  // grid-stride: on the steps that do not re-bin these launches return at once
     launch_cell_scan(c, clk, qf, d.start);
     launch_scatter_reorder(c, clk, qf,
                            reorder_args(c->kpos.get(), c->kvel.get(), c->kdrho.get(), c->kmass.get(), c->kid.get(), d, nullptr,
                                         c->slot_of_id.get()),
                            d, kRebinBlocks);
-    launch(c, "k_slab_sendlist", k_slab_sendlist, dim3(std::min(c->n_blocks_flat, kRebinBlocks)), dim3(kBlock), (const Clock *)clk,
-           q, c->grid, d, c->pack, c->lists, c->flags.get(), 0);
-    launch(c, "k_slab_seal_ids", k_slab_seal_ids, dim3(1), dim3(1), (const Clock *)clk, q, c->pack, c->lists, 0);
+    launch(c, "k_slab_sendlist", k_slab_sendlist, dim3(std::min(c->n_blocks_flat, kTicketBlocks)), dim3(kBlock), (const Clock *)clk,
+           q, c->grid, d, c->pack, c->lists, c->flags.get(), 0, c->ticket.get());
 }
 
 void slab_phase4(sphx_ctx *c)  // host bookkeeping of the step (the ids made in phase 3 travel with the next step's message A)
@@ -2159,9 +2293,8 @@ void slab_lists_out(sphx_ctx *c)
 {
     const FluidSet d = c->view(c->cur, 0);
     SPHX_HIP(hipMemsetAsync(c->send_cnt.get(), 0, 2 * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_slab_sendlist, dim3(std::min(c->n_blocks_flat, 4096)), dim3(kBlock), 0, c->stream,
-                       (const Clock *)c->clock.get(), 0, c->grid, d, c->pack, c->lists, c->flags.get(), 1);
-    hipLaunchKernelGGL(k_slab_seal_ids, dim3(1), dim3(1), 0, c->stream, (const Clock *)c->clock.get(), 0, c->pack, c->lists, 1);
+    hipLaunchKernelGGL(k_slab_sendlist, dim3(std::min(c->n_blocks_flat, kTicketBlocks)), dim3(kBlock), 0, c->stream,
+                       (const Clock *)c->clock.get(), 0, c->grid, d, c->pack, c->lists, c->flags.get(), 1, c->ticket.get());
 }
 void slab_lists_in(sphx_ctx *c)
 {
@@ -2182,57 +2315,53 @@ void slab_local_maxima(sphx_ctx *c)  // arming: max |v| of the owned particles o
 
 }  // namespace
 
-SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
-{
-    SPHX_TRY
-    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
-    require(c->comm != nullptr, "SPHX:Slab:rccl", "sphx_slab_comm_init first");
-    require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
-    Rccl &R = Rccl::get();
-    hipStream_t st = c->stream;
-    const int left = (c->rank + c->n_ranks - 1) % c->n_ranks, right = (c->rank + 1) % c->n_ranks;
-    const size_t n_msg = 1 + 7 * (size_t)c->msg_cap, n_ids = 1 + (size_t)c->msg_cap;
-    double *sl = c->msg_sl.get(), *sr = c->msg_sr.get(), *rl = c->msg_rl.get(), *rr = c->msg_rr.get();
-    double *vl = c->vmax_l.get(), *vg = c->vmax_g.get();
-    const bool skinned = c->rebuild_every > 1;
+namespace {
+
+constexpr int kSlabGraphSteps = 10;  // steps per replay of a slab's step graph (even: the state parity comes back)
+
+// ---- one rank per process: the steps of sphx_slab_run on the context's stream (eagerly, or under stream capture) ----
+struct RcclLoop {
+    sphx_ctx *c;
+    Rccl &R;
+    hipStream_t st;
+    int left, right;
+    size_t n_msg, n_ids;
+    explicit RcclLoop(sphx_ctx *ctx)
+        : c(ctx), R(Rccl::get()), st(ctx->stream), left((ctx->rank + ctx->n_ranks - 1) % ctx->n_ranks),
+          right((ctx->rank + 1) % ctx->n_ranks), n_msg(1 + 7 * (size_t)ctx->msg_cap), n_ids(1 + (size_t)ctx->msg_cap) {}
     // My left message is my left neighbour's "from the right" message and vice versa; with two ranks both go to the same
     // peer, which posts its receives in the order the sends are posted here.
-    auto ring = [&](const void *to_l, const void *to_r, void *from_l, void *from_r, size_t count, ncclDataType_t ty) {
+    void ring(const void *to_l, const void *to_r, void *from_l, void *from_r, size_t count, ncclDataType_t ty)
+    {
         R.check(R.GroupStart(), "ncclGroupStart");
         R.check(R.Send(to_l, count, ty, left, c->comm, st), "ncclSend");
         R.check(R.Send(to_r, count, ty, right, c->comm, st), "ncclSend");
         R.check(R.Recv(from_r, count, ty, right, c->comm, st), "ncclRecv");
         R.check(R.Recv(from_l, count, ty, left, c->comm, st), "ncclRecv");
         R.check(R.GroupEnd(), "ncclGroupEnd");
-    };
+    }
     // the exchange of a skinned step: message A and the list ids of the previous step in ONE group
-    auto ring_step = [&]() {
+    void ring_step()
+    {
         R.check(R.GroupStart(), "ncclGroupStart");
-        R.check(R.Send(sl, n_msg, ncclDouble, left, c->comm, st), "ncclSend");
-        R.check(R.Send(sr, n_msg, ncclDouble, right, c->comm, st), "ncclSend");
+        R.check(R.Send(c->msg_sl.get(), n_msg, ncclDouble, left, c->comm, st), "ncclSend");
+        R.check(R.Send(c->msg_sr.get(), n_msg, ncclDouble, right, c->comm, st), "ncclSend");
         R.check(R.Send(c->ids_s_[0].get(), n_ids, ncclInt32, left, c->comm, st), "ncclSend");
         R.check(R.Send(c->ids_s_[1].get(), n_ids, ncclInt32, right, c->comm, st), "ncclSend");
-        R.check(R.Recv(rr, n_msg, ncclDouble, right, c->comm, st), "ncclRecv");
-        R.check(R.Recv(rl, n_msg, ncclDouble, left, c->comm, st), "ncclRecv");
+        R.check(R.Recv(c->msg_rr.get(), n_msg, ncclDouble, right, c->comm, st), "ncclRecv");
+        R.check(R.Recv(c->msg_rl.get(), n_msg, ncclDouble, left, c->comm, st), "ncclRecv");
         R.check(R.Recv(c->ids_r_[1].get(), n_ids, ncclInt32, right, c->comm, st), "ncclRecv");
         R.check(R.Recv(c->ids_r_[0].get(), n_ids, ncclInt32, left, c->comm, st), "ncclRecv");
         R.check(R.GroupEnd(), "ncclGroupEnd");
-    };
-    // arm the clock with the global max |v| of the current state
-    slab_local_maxima(c);
-    R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
-    arm_clock(c, t_target, (long long)n_steps, c->cur, (const double *)vg);
-    if (skinned && !c->lists_ready) {
-        slab_lists_out(c);
-        ring(c->ids_s_[0].get(), c->ids_s_[1].get(), c->ids_r_[0].get(), c->ids_r_[1].get(), n_ids, ncclInt32);
-        slab_lists_in(c);
     }
-    for (int64_t k = 0; k < n_steps; ++k) {
-        if (!skinned) {
-            slab_compute_impl(c, sl, sr, vl);
+    void step()
+    {
+        double *vl = c->vmax_l.get(), *vg = c->vmax_g.get();
+        if (c->rebuild_every <= 1) {
+            slab_compute_impl(c, c->msg_sl.get(), c->msg_sr.get(), vl);
             R.check(R.AllReduce(vl, vg, 1, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
-            ring(sl, sr, rl, rr, n_msg, ncclDouble);
-            slab_finish_impl(c, rl, rr, vg);
+            ring(c->msg_sl.get(), c->msg_sr.get(), c->msg_rl.get(), c->msg_rr.get(), n_msg, ncclDouble);
+            slab_finish_impl(c, c->msg_rl.get(), c->msg_rr.get(), vg);
         } else {
             slab_phase1(c);
             R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
@@ -2242,77 +2371,55 @@ SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
             slab_phase4(c);
         }
     }
-    SPHX_HIP(hipGetLastError());
-    return SPHX_OK;
-    SPHX_CATCH
-}
+};
 
-SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int64_t n_steps)
-{
-    SPHX_TRY
-    require(ctxs != nullptr && n >= 2 && n <= 16, "SPHX:Slab:group", "a ring needs 2..16 slab contexts");
-    require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
+// ---- all slabs of the ring in one process: the same steps with device-to-device copies and events ----
+struct GroupLoop {
+    sphx_ctx **ctxs;
+    int n;
     PtrList vls{};
-    for (int r = 0; r < n; ++r) {
-        sphx_ctx *c = ctxs[r];
-        require(c != nullptr && c->is_slab && c->rank == r && c->n_ranks == n, "SPHX:Slab:group",
-                "ctxs[r] must be slab r of an n-slab ring");
-        require(c->msg_cap == ctxs[0]->msg_cap && c->rebuild_every == ctxs[0]->rebuild_every, "SPHX:Slab:group",
-                "slabs of one ring share the message capacity and the re-binning interval");
-        slab_native_buffers(c);
-        if (!c->ev_computed) {
-            SPHX_HIP(hipEventCreateWithFlags(&c->ev_computed, hipEventDisableTiming));
-            SPHX_HIP(hipEventCreateWithFlags(&c->ev_received, hipEventDisableTiming));
-        }
-        vls.p[r] = c->vmax_l.get();
+    bool skinned;
+    bool serial = false;  // every slab enqueues on the same stream: stream order is the only ordering needed
+    size_t msg_bytes, ids_bytes;
+    GroupLoop(sphx_ctx **cs, int count) : ctxs(cs), n(count)
+    {
+        for (int r = 0; r < n; ++r) vls.p[r] = ctxs[r]->vmax_l.get();
+        skinned = ctxs[0]->rebuild_every > 1;
+        msg_bytes = (1 + 7 * (size_t)ctxs[0]->msg_cap) * sizeof(double);
+        ids_bytes = (1 + (size_t)ctxs[0]->msg_cap) * sizeof(int);
     }
-    const bool skinned = ctxs[0]->rebuild_every > 1;
-    const size_t msg_bytes = (1 + 7 * (size_t)ctxs[0]->msg_cap) * sizeof(double);
-    const size_t ids_bytes = (1 + (size_t)ctxs[0]->msg_cap) * sizeof(int);
     // A phase boundary of the ring: every rank records "my outputs of this phase are complete" and, before it touches
     // anything another rank produced (or overwrites what another rank may still be reading), waits for all the others.
-    auto done = [&](hipEvent_t sphx_ctx::*ev) {
+    void done(hipEvent_t sphx_ctx::*ev)
+    {
+        if (serial) return;
         for (int r = 0; r < n; ++r) SPHX_HIP(hipEventRecord(ctxs[r]->*ev, ctxs[r]->stream));
-    };
-    auto wait_others = [&](int r, hipEvent_t sphx_ctx::*ev) {
+    }
+    void wait_others(int r, hipEvent_t sphx_ctx::*ev)
+    {
+        if (serial) return;
         for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(ctxs[r]->stream, ctxs[o]->*ev, 0));
-    };
-    auto max_of_all = [&](sphx_ctx *c) {
-        hipLaunchKernelGGL(k_max_of, dim3(1), dim3(2), 0, c->stream, n, vls, c->vmax_g.get());
-    };
-    auto copy_msgs = [&](int r) {  // what my ring neighbours addressed to me
+    }
+    void max_of_all(sphx_ctx *c) { hipLaunchKernelGGL(k_max_of, dim3(1), dim3(2), 0, c->stream, n, vls, c->vmax_g.get()); }
+    void copy_msgs(int r)  // what my ring neighbours addressed to me
+    {
         sphx_ctx *c = ctxs[r], *L = ctxs[(r + n - 1) % n], *Rr = ctxs[(r + 1) % n];
         SPHX_HIP(hipMemcpyAsync(c->msg_rl.get(), L->msg_sr.get(), msg_bytes, hipMemcpyDeviceToDevice, c->stream));
         SPHX_HIP(hipMemcpyAsync(c->msg_rr.get(), Rr->msg_sl.get(), msg_bytes, hipMemcpyDeviceToDevice, c->stream));
-    };
-    auto copy_ids = [&](int r) {
+    }
+    void copy_ids(int r)
+    {
         sphx_ctx *c = ctxs[r], *L = ctxs[(r + n - 1) % n], *Rr = ctxs[(r + 1) % n];
         SPHX_HIP(hipMemcpyAsync(c->ids_r_[0].get(), L->ids_s_[1].get(), ids_bytes, hipMemcpyDeviceToDevice, c->stream));
         SPHX_HIP(hipMemcpyAsync(c->ids_r_[1].get(), Rr->ids_s_[0].get(), ids_bytes, hipMemcpyDeviceToDevice, c->stream));
-    };
-    // arm: local maxima -> global -> clock; first exchange lists
-    for (int r = 0; r < n; ++r) slab_local_maxima(ctxs[r]);
-    done(&sphx_ctx::ev_computed);
-    for (int r = 0; r < n; ++r) {
-        sphx_ctx *c = ctxs[r];
-        wait_others(r, &sphx_ctx::ev_computed);
-        max_of_all(c);
-        arm_clock(c, t_target, (long long)n_steps, c->cur, (const double *)c->vmax_g.get());
-        if (skinned && !c->lists_ready) slab_lists_out(c);
     }
-    done(&sphx_ctx::ev_received);
-    if (skinned && !ctxs[0]->lists_ready) {
-        for (int r = 0; r < n; ++r) {
-            wait_others(r, &sphx_ctx::ev_received);
-            copy_ids(r);
-            slab_lists_in(ctxs[r]);
-        }
-        done(&sphx_ctx::ev_received);
-    }
-    for (int64_t k = 0; k < n_steps; ++k) {
+    // entry_waits: the slabs first wait until the others have consumed their previous messages and maxima (not the first
+    // step of a captured graph: what came before is ordered by the launch, see replay())
+    void step(bool entry_waits = true)
+    {
         for (int r = 0; r < n; ++r) {
             sphx_ctx *c = ctxs[r];
-            wait_others(r, &sphx_ctx::ev_received);  // the others have consumed my previous messages and maxima
+            if (entry_waits) wait_others(r, &sphx_ctx::ev_received);
             if (skinned) slab_phase1(c);
             else slab_compute_impl(c, c->msg_sl.get(), c->msg_sr.get(), c->vmax_l.get());
         }
@@ -2326,7 +2433,7 @@ SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int
             }
             done(&sphx_ctx::ev_received);
             for (int r = 0; r < n; ++r) slab_finish_impl(ctxs[r], ctxs[r]->msg_rl.get(), ctxs[r]->msg_rr.get(), ctxs[r]->vmax_g.get());
-            continue;
+            return;
         }
         for (int r = 0; r < n; ++r) {  // "all-reduce", decision, message A
             sphx_ctx *c = ctxs[r];
@@ -2348,7 +2455,195 @@ SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int
         }
         done(&sphx_ctx::ev_received);
     }
+    bool graph_matches() const
+    {
+        const sphx_ctx *c0 = ctxs[0];
+        if (!c0->steps_graph || (int)c0->steps_graph_ring.size() != n || c0->steps_graph_cur != c0->cur) return false;
+        for (int r = 0; r < n; ++r) if (c0->steps_graph_ring[r] != ctxs[r]) return false;
+        return true;
+    }
+    // one replay of slab 0's step graph: everything the slabs enqueued before it is ordered ahead of it, everything they
+    // enqueue afterwards behind it
+    void replay()
+    {
+        sphx_ctx *c0 = ctxs[0];
+        for (int r = 1; r < n; ++r) {
+            SPHX_HIP(hipEventRecord(ctxs[r]->ev_join, ctxs[r]->stream));
+            SPHX_HIP(hipStreamWaitEvent(c0->stream, ctxs[r]->ev_join, 0));
+        }
+        SPHX_HIP(hipGraphLaunch(c0->steps_graph, c0->stream));
+        SPHX_HIP(hipEventRecord(c0->ev_fork, c0->stream));
+        for (int r = 1; r < n; ++r) SPHX_HIP(hipStreamWaitEvent(ctxs[r]->stream, c0->ev_fork, 0));
+        done(&sphx_ctx::ev_received);  // (the eager steps that may follow wait for these)
+        for (int r = 0; r < n; ++r) ctxs[r]->slab_steps_enqueued += kSlabGraphSteps;
+    }
+};
+
+void check_ring(sphx_ctx **ctxs, int n)
+{
+    require(ctxs != nullptr && n >= 2 && n <= 16, "SPHX:Slab:group", "a ring needs 2..16 slab contexts");
+    for (int r = 0; r < n; ++r) {
+        sphx_ctx *c = ctxs[r];
+        require(c != nullptr && c->is_slab && c->rank == r && c->n_ranks == n, "SPHX:Slab:group",
+                "ctxs[r] must be slab r of an n-slab ring");
+        require(c->msg_cap == ctxs[0]->msg_cap && c->rebuild_every == ctxs[0]->rebuild_every, "SPHX:Slab:group",
+                "slabs of one ring share the message capacity and the re-binning interval");
+        slab_native_buffers(c);
+        if (!c->ev_computed) {
+            SPHX_HIP(hipEventCreateWithFlags(&c->ev_computed, hipEventDisableTiming));
+            SPHX_HIP(hipEventCreateWithFlags(&c->ev_received, hipEventDisableTiming));
+            SPHX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            SPHX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+    }
+}
+
+}  // namespace
+
+SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
+{
+    SPHX_TRY
+    require(c != nullptr && c->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    require(c->comm != nullptr, "SPHX:Slab:rccl", "sphx_slab_comm_init first");
+    require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
+    RcclLoop loop(c);
+    double *vl = c->vmax_l.get(), *vg = c->vmax_g.get();
+    const bool skinned = c->rebuild_every > 1;
+    // arm the clock with the global max |v| of the current state: after a step the clock holds it already (the all-reduced
+    // value that step's dt rule used); only a state that has never been stepped needs the reduction (k_vmax_init is one
+    // workgroup over the whole slab: 0.9 ms at 0.76 M particles)
+    if (c->slab_steps_enqueued == 0) {
+        slab_local_maxima(c);
+        loop.R.check(loop.R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, loop.st), "ncclAllReduce");
+        arm_clock(c, t_target, (long long)n_steps, c->cur, (const double *)vg);
+    } else {
+        arm_clock(c, t_target, (long long)n_steps, c->cur, (const double *)nullptr);
+    }
+    if (skinned && !c->lists_ready) {
+        slab_lists_out(c);
+        loop.ring(c->ids_s_[0].get(), c->ids_s_[1].get(), c->ids_r_[0].get(), c->ids_r_[1].get(), loop.n_ids, ncclInt32);
+        slab_lists_in(c);
+    }
+    int64_t k = 0;
+    if (c->steps_graph && c->steps_graph_cur == c->cur)  // whole replays of the step graph (sphx_slab_graph_prepare) ...
+        for (; n_steps - k >= kSlabGraphSteps; k += kSlabGraphSteps) {
+            SPHX_HIP(hipGraphLaunch(c->steps_graph, loop.st));
+            c->slab_steps_enqueued += kSlabGraphSteps;
+        }
+    for (; k < n_steps; ++k) loop.step();  // ... the rest step by step
     SPHX_HIP(hipGetLastError());
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int64_t n_steps)
+{
+    SPHX_TRY
+    check_ring(ctxs, n);
+    require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
+    GroupLoop loop(ctxs, n);
+    // arm: local maxima -> global -> clock (a state that has been stepped: the clock holds the global maximum already, see
+    // sphx_slab_run); first exchange lists
+    bool fresh_state = false;
+    for (int r = 0; r < n; ++r) fresh_state = fresh_state || ctxs[r]->slab_steps_enqueued == 0;
+    if (fresh_state)
+        for (int r = 0; r < n; ++r) slab_local_maxima(ctxs[r]);
+    loop.done(&sphx_ctx::ev_computed);
+    for (int r = 0; r < n; ++r) {
+        sphx_ctx *c = ctxs[r];
+        loop.wait_others(r, &sphx_ctx::ev_computed);
+        if (fresh_state) loop.max_of_all(c);
+        arm_clock(c, t_target, (long long)n_steps, c->cur, fresh_state ? (const double *)c->vmax_g.get() : (const double *)nullptr);
+        if (loop.skinned && !c->lists_ready) slab_lists_out(c);
+    }
+    loop.done(&sphx_ctx::ev_received);
+    if (loop.skinned && !ctxs[0]->lists_ready) {
+        for (int r = 0; r < n; ++r) {
+            loop.wait_others(r, &sphx_ctx::ev_received);
+            loop.copy_ids(r);
+            slab_lists_in(ctxs[r]);
+        }
+        loop.done(&sphx_ctx::ev_received);
+    }
+    int64_t k = 0;
+    if (loop.graph_matches())
+        for (; n_steps - k >= kSlabGraphSteps; k += kSlabGraphSteps) loop.replay();
+    for (; k < n_steps; ++k) loop.step();
+    SPHX_HIP(hipGetLastError());
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+// Capture kSlabGraphSteps whole steps of the native loop into one graph; sphx_slab_run / sphx_slab_group_run then replay it
+// for every full batch of that many steps and launch only the remainder step by step.  n = 1: the context of this
+// process's rank (sphx_slab_run; the RCCL calls are captured with the kernels -- every rank of the communicator must
+// make this call at the same point of its sequence, because the graph is warmed with one idle replay that exchanges
+// messages); n >= 2: an in-process ring (the graph is held by slab 0).  The loop must have run at least two steps
+// (communicator channels, exchange lists and pools are set up by then: nothing may allocate during capture).  Without
+// this call the loops stay eager; a failed capture leaves them eager and reports the error.
+SPHX_EXPORT int sphx_slab_graph_prepare(sphx_ctx **ctxs, int n)
+{
+    SPHX_TRY
+    require(ctxs != nullptr && n >= 1 && ctxs[0] != nullptr && ctxs[0]->is_slab, "SPHX:Slab:ctx", "not a slab context");
+    sphx_ctx *c0 = ctxs[0];
+    require(c0->rebuild_every > 1, "SPHX:Slab:protocol", "step graphs are for skinned slabs (rebuild_every != 1)");
+    if (n == 1) require(c0->comm != nullptr, "SPHX:Slab:rccl", "sphx_slab_comm_init first");
+    else check_ring(ctxs, n);
+    for (int r = 0; r < n; ++r) {
+        require(ctxs[r]->lists_ready && ctxs[r]->slab_steps_enqueued >= 2, "SPHX:Slab:graph",
+                "run at least two steps before capturing the step graph");
+        SPHX_HIP(hipStreamSynchronize(ctxs[r]->stream));
+    }
+    if (c0->steps_graph) { (void)hipGraphExecDestroy(c0->steps_graph); c0->steps_graph = nullptr; }
+    const int64_t enq0 = c0->slab_steps_enqueued;
+    const int cur0 = c0->cur;
+    hipStream_t s0 = c0->stream;
+    hipGraph_t g = nullptr;
+    // An in-process ring is captured as ONE chain on slab 0's stream (the slabs take turns phase by phase): a graph whose
+    // branches meet at every phase boundary replays slower than the eager loop on ROCm 7.2 (0.25 M particles per slab: 334
+    // against 289 us/step), and the slabs of a ring share one device anyway.
+    std::vector<hipStream_t> own_streams(n);
+    for (int r = 0; r < n; ++r) { own_streams[r] = ctxs[r]->stream; ctxs[r]->stream = s0; }
+    auto restore_streams = [&]() { for (int r = 0; r < n; ++r) ctxs[r]->stream = own_streams[r]; };
+    const hipError_t e_begin = hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed);
+    if (e_begin != hipSuccess) { restore_streams(); SPHX_HIP(e_begin); }
+    try {
+        if (n == 1) {
+            RcclLoop loop(c0);
+            for (int k = 0; k < kSlabGraphSteps; ++k) loop.step();
+        } else {
+            GroupLoop loop(ctxs, n);
+            loop.serial = true;
+            for (int k = 0; k < kSlabGraphSteps; ++k) loop.step();
+        }
+    } catch (...) {
+        abandon_capture(s0);
+        restore_streams();
+        for (int r = 0; r < n; ++r) { ctxs[r]->cur = cur0; ctxs[r]->slab_steps_enqueued = enq0; }
+        throw;
+    }
+    restore_streams();
+    for (int r = 0; r < n; ++r) ctxs[r]->slab_steps_enqueued -= kSlabGraphSteps;  // nothing has executed
+    const hipError_t e_end = hipStreamEndCapture(s0, &g);
+    if (e_end != hipSuccess) { (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g); SPHX_HIP(e_end); }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e_inst = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    SPHX_HIP(e_inst);
+    // warm replay with the clock disarmed: every kernel returns at once, the messages that travel are ignored (ids made by
+    // the last real step are delivered -- that is what the next real step would have done first)
+    for (int r = 0; r < n; ++r) hipLaunchKernelGGL(k_disarm, dim3(1), dim3(1), 0, ctxs[r]->stream, ctxs[r]->clock.get());
+    c0->steps_graph = exec;
+    c0->steps_graph_cur = cur0;
+    c0->steps_graph_ring.assign(ctxs, ctxs + n);
+    if (n == 1) {
+        SPHX_HIP(hipGraphLaunch(exec, s0));
+    } else {
+        GroupLoop loop(ctxs, n);
+        loop.replay();
+        for (int r = 0; r < n; ++r) ctxs[r]->slab_steps_enqueued -= kSlabGraphSteps;
+    }
+    for (int r = 0; r < n; ++r) SPHX_HIP(hipStreamSynchronize(ctxs[r]->stream));
     return SPHX_OK;
     SPHX_CATCH
 }

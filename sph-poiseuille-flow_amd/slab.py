@@ -111,9 +111,10 @@ class HipSlabEngine:
     """libsphx slab context of one rank; device buffers are torch tensors so RCCL can move them."""
 
     def __init__(self, prm, parts, rank, world, device, lanes_per_particle=0, halo_cols=HALO_COLS, t_end=None,
-                 pos=None, vel=None, drho_dt=None, native=False, rebuild_every=0, skin_h=0.0):
+                 pos=None, vel=None, drho_dt=None, native=False, rebuild_every=0, skin_h=0.0, hip_stream=None):
         """native=True: the context runs on a stream of its own and keeps its message buffers inside the library (the
-        native loop: run() over RCCL, or group_run() for a ring living in one process); no torch tensors involved."""
+        native loop: run() over RCCL, or group_run() for a ring living in one process); no torch tensors involved.
+        hip_stream (native only): a hipStream_t handle the context runs on instead (profiling: a ring on ONE stream)."""
         from . import capi
         self.capi = capi
         self.rank, self.world, self.native = rank, world, native
@@ -138,7 +139,7 @@ class HipSlabEngine:
                                                capi.ptr(pos), capi.ptr(vel), capi.ptr(drho), capi.ptr(mass), capi.ptr(wv),
                                                C.c_double(0.0), C.c_int64(0), C.c_int(rank), C.c_int(world),
                                                C.c_int(halo_cols),
-                                               C.c_void_p(None if native else self.stream.cuda_stream)))
+                                               C.c_void_p(hip_stream if native else self.stream.cuda_stream)))
         self.n_total_global = nt
         if native:
             return
@@ -191,6 +192,11 @@ class HipSlabEngine:
     def stream_ctx(self):
         return self.torch.cuda.stream(self.stream)
 
+    def rebuild_every(self) -> int:
+        k = C.c_int(0)
+        self.capi.check(self.capi.lib().sphx_ctx_grid_policy(self._h, C.byref(k), None, None, None))
+        return k.value
+
     # ---- native loop --------------------------------------------------------------------------------
     @staticmethod
     def unique_id(capi) -> bytes:
@@ -211,6 +217,14 @@ class HipSlabEngine:
         capi = engines[0].capi
         arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
         capi.check(capi.lib().sphx_slab_group_run(arr, C.c_int(len(engines)), C.c_double(t_target), C.c_int64(n_steps)))
+
+    @staticmethod
+    def graph_prepare(engines):
+        """Capture ten whole steps (kernels + RCCL calls, or the copies of an in-process ring) into one hipGraph that run()
+        / group_run() replay from now on.  One engine: this rank's (collective: every rank calls it at the same point)."""
+        capi = engines[0].capi
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        capi.check(capi.lib().sphx_slab_graph_prepare(arr, C.c_int(len(engines))))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -300,23 +314,105 @@ def dt_upper_bound(prm) -> float:
                0.25 * math.sqrt(prm.h / max(abs(prm.gravity_g), 1e-12)))
 
 
+class Watchdog:
+    """A collective that never returns (a rank that died inside ncclCommInitRank, a wedged first exchange) would hold a
+    whole node until somebody notices: every potentially blocking phase of the multi-GPU bench runs under this timer,
+    which ends THIS process with exit code 3 and a message when the phase overruns."""
+
+    def __init__(self, what: str, seconds: float, rank: int):
+        import threading
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.what, self.seconds, self.rank = what, seconds, rank
+
+    def _fire(self):
+        import sys
+        sys.stderr.write(f"[sphx slab] rank {self.rank}: '{self.what}' did not finish within {self.seconds:.0f} s -- giving up "
+                         f"(exit 3) instead of hanging the node\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+
+
+def all_agree(dist, ok: bool, group=None) -> bool:
+    """True on every rank iff `ok` on every rank (control plane: CPU tensor, gloo)."""
+    import torch
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
+def join_native_ring(make_engine, capi, rank, dist, group=None, timeout_s=240.0):
+    """Collective over `group` (a gloo control plane): every rank returns an engine whose RCCL communicator is up, or every
+    rank raises RuntimeError.  ncclCommInitRank is itself collective -- a rank that cannot load librccl or cannot build its
+    slab must not leave the others waiting inside it, so the ranks first agree that everything local succeeded."""
+    eng, why = None, None
+    try:
+        capi.check(capi.lib().sphx_comm_available())
+        eng = make_engine()
+    except Exception as e:  # noqa: BLE001 -- whatever went wrong locally, the other ranks must hear about it
+        why = f"rank {rank}: {e}"
+    if not all_agree(dist, why is None, group):
+        if eng is not None:
+            eng.close()
+        raise RuntimeError("native RCCL slab loop unavailable: " + (why or "another rank could not load librccl / build its slab"))
+    ident = [None]
+    if rank == 0:
+        try:
+            ident = [HipSlabEngine.unique_id(capi)]
+        except Exception as e:  # noqa: BLE001
+            why = f"rank 0: {e}"
+    dist.broadcast_object_list(ident, src=0, group=group)
+    if ident[0] is None:
+        eng.close()
+        raise RuntimeError("native RCCL slab loop unavailable: " + (why or "rank 0 could not make a communicator id"))
+    try:
+        with Watchdog("ncclCommInitRank", timeout_s, rank):
+            eng.comm_init(ident[0])
+    except Exception as e:  # noqa: BLE001
+        why = f"rank {rank}: {e}"
+    if not all_agree(dist, why is None, group):
+        eng.close()
+        raise RuntimeError("native RCCL slab loop unavailable: " + (why or "ncclCommInitRank failed on another rank"))
+    return eng
+
+
 def bench_main(args, rank, world, local_rank):
     """bench.py --gpus N (N > 1).  Headline: weak scaling of the headline configuration -- every GPU holds one
     dp = 0.025, DL = 3 channel section (5 760 particles), the N-GPU channel is DL = 3 N long.  `aux`: the
-    6.1 M-particle channel (C5) cut into N slabs -- the strong-scaling case the north star quotes."""
+    6.1 M-particle channel (C5) cut into N slabs -- the strong-scaling case the north star quotes.
+
+    Control plane (id broadcast, agreement votes, barriers, the timing reduction) = torch.distributed on gloo; data plane =
+    the library's own loop over its own dlopen'ed RCCL communicator (SPHX_SLAB_LOOP=native, the default with a GPU per
+    rank) -- the only RCCL instance in the process.  When that loop cannot be brought up the run FAILS (non-zero exit,
+    reason on stderr); it never measures something else silently.  SPHX_SLAB_LOOP=python asks for the caller-driven
+    protocol over torch.distributed's nccl backend instead (opt-in; ten times slower at 5 760 particles per slab);
+    SPHX_DIST_BACKEND=gloo is the rehearsal with ranks sharing one GPU (messages staged through host memory)."""
     import importlib
+    import sys
     import torch
     import torch.distributed as dist
     pkg = importlib.import_module(__package__)
     cfg, geo, capi = pkg.config, pkg.geometry, pkg.capi
-    backend = os.environ.get("SPHX_DIST_BACKEND", "nccl")  # "gloo": rehearsal with ranks sharing one GPU
+    rehearsal = os.environ.get("SPHX_DIST_BACKEND", "nccl") == "gloo"  # ranks may share one GPU
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend)
-    # the library's own loop over RCCL unless told otherwise (or unless the ranks cannot have a GPU each)
-    native = dist.get_backend() == "nccl" and os.environ.get("SPHX_SLAB_LOOP", "native") == "native"
+    loop = os.environ.get("SPHX_SLAB_LOOP", "native")
+    if loop not in ("native", "python"):
+        raise SystemExit(f"SPHX_SLAB_LOOP={loop}: expected 'native' or 'python'")
+    native = loop == "native" and not rehearsal
+    if native and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} with {torch.cuda.device_count()} visible device(s): RCCL needs one GPU per rank "
+                         f"(SPHX_DIST_BACKEND=gloo rehearses with ranks sharing a GPU)")
+    dist.init_process_group("gloo")  # control plane only
+    data_group = None
+    if not native and not rehearsal:
+        data_group = dist.new_group(ranks=list(range(world)), backend="nccl")  # the Python loop's transport (opt-in)
     workloads = {"C1": dict(dp=0.04, DL=3.0), "C2": dict(dp=0.025, DL=3.0), "C3": dict(dp=0.01, DL=6.0),
                  "C4": dict(dp=0.005, DL=12.0), "C5": dict(dp=0.002, DL=24.0)}
 
@@ -331,71 +427,64 @@ def bench_main(args, rank, world, local_rank):
         else:
             pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
             start = "developed (analytic parabola + 0.05dp jitter, seed 12345)"
-        use_native, why_not = native, None
-        eng = None
-        if use_native:
-            # every rank must end up on the same path: a rank that cannot join the RCCL communicator (librccl missing,
-            # ncclCommInitRank refused ...) tells the others and all fall back to the caller-driven protocol
-            try:
-                ident = [HipSlabEngine.unique_id(capi) if rank == 0 else None]
-            except capi.SphxError as e:
-                ident, why_not = [None], str(e)
-            dist.broadcast_object_list(ident, src=0)
-            if ident[0] is not None:
-                try:
-                    eng = HipSlabEngine(prm, parts, rank, world, local_rank, lanes_per_particle=args.lpp, t_end=1e9, pos=pos,
-                                        vel=vel, native=True)
-                    eng.comm_init(ident[0])
-                except capi.SphxError as e:
-                    why_not = str(e)
-            failed = torch.tensor([1 if (why_not or ident[0] is None) else 0], device=torch.device("cuda", local_rank))
-            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-            if int(failed.item()):
-                use_native = False
-                if eng is not None:
-                    eng.close()
-        if use_native:
+        if native:
+            eng = join_native_ring(lambda: HipSlabEngine(prm, parts, rank, world, local_rank, lanes_per_particle=args.lpp,
+                                                         t_end=1e9, pos=pos, vel=vel, native=True), capi, rank, dist)
             run = lambda n: (eng.run(n), eng.sync())[1]
+            graph = os.environ.get("SPHX_SLAB_GRAPH", "0") == "1"  # opt-in: ten steps per replayed hipGraph, RCCL calls inside
         else:
+            graph = False
             eng = HipSlabEngine(prm, parts, rank, world, local_rank, lanes_per_particle=args.lpp, t_end=1e9, pos=pos, vel=vel)
-            drv = SlabDriver(eng, RingExchange(rank, world))
+            drv = SlabDriver(eng, RingExchange(rank, world, group=data_group))
             run = drv.run_steps
-        if warmup > 0:
-            run(warmup)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        st = run(steps)
-        torch.cuda.synchronize()
-        dist.barrier()
-        seconds = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
-                               device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(seconds, op=dist.ReduceOp.MAX)
+        with Watchdog(f"{name}: warm-up ({warmup} steps)", 600.0, rank):
+            if warmup > 0:
+                run(warmup)
+            if graph:
+                if warmup < 2:
+                    run(2)
+                HipSlabEngine.graph_prepare([eng])
+            dist.barrier()
+            torch.cuda.synchronize()
+        with Watchdog(f"{name}: timed region ({steps} steps)", 900.0, rank):
+            t0 = time.perf_counter()
+            st = run(steps)
+            torch.cuda.synchronize()
+            dist.barrier()
+            seconds = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(seconds, op=dist.ReduceOp.MAX)
         seconds = float(seconds.item())
         nt, lay = parts["n_total"], eng.layout()
+        K = eng.rebuild_every()
         eng.close()
         alg = (528 * parts["n_fluid"] + 120 * parts["n_wall"]) * steps / seconds / 1e9
-        loop = ("native step loop in libsphx over RCCL: re-binning every 5th step, per step one group of ncclSend/ncclRecv "
-                "with both ring neighbours (state + list ids) and one 16-byte ncclAllReduce(max)"
-                if use_native else f"Python step loop over torch.distributed[{dist.get_backend()}], re-binning every step"
-                                   + (" (messages staged through host memory)" if dist.get_backend() != "nccl" else "")
-                                   + (f" -- native RCCL loop unavailable: {why_not}" if native and why_not else ""))
+        how = (f"native step loop in libsphx over its own RCCL communicator (control plane: gloo): re-binning every {K}th step or "
+               "when the all-reduced drift hits the bound, per step one group of ncclSend/ncclRecv with both ring neighbours "
+               "(state + list ids) and one 16-byte ncclAllReduce(max)" + ("; ten steps per replayed hipGraph" if graph else "; launched step by step")
+               if native else "Python step loop (compute -> exchange -> finish), re-binning every step, over torch.distributed["
+                              + ("gloo, messages staged through host memory" if rehearsal else "nccl") + "]")
         return dict(value=nt * steps / seconds, ms_per_step=1e3 * seconds / steps, steps=steps, warmup=warmup,
                     scaling="strong" if strong else "weak",
                     workload=f"{name} x{world if not strong else 1}: dp={prm.dp}, DL={prm.DL}, DH={prm.DH}, "
                              f"n_fluid={parts['n_fluid']}, n_wall={parts['n_wall']}, n_total={nt}; start={start}",
-                    parallelism=f"{world} x-slabs (one rank per GPU), {HALO_COLS}-column halo, {loop}", slab0=lay,
+                    parallelism=f"{world} x-slabs (one rank per GPU), {HALO_COLS}-column halo, {how}", slab0=lay,
+                    native_loop=bool(native),
                     roofline={"bound": "hbm", "achieved": alg, "peak": 8000.0 * world, "unit": "GB/s",
                               "frac": alg / (8000.0 * world), "traffic": None, "kernel": "whole step, all ranks"},
                     sim={"t": st["t"], "dt": st["dt_last"], "vmax": st["vmax"]})
 
-    head = run_case(args.workload or "C2", args.steps, args.warmup)
+    try:
+        head = run_case(args.workload or "C2", args.steps, args.warmup)
+    except RuntimeError as e:  # join_native_ring: raised on every rank
+        sys.stderr.write(f"[sphx slab] rank {rank}: {e}\n")
+        dist.destroy_process_group()
+        raise SystemExit(4)
     aux = {}
     if args.workload is None and not args.no_aux:
         try:  # every rank takes the same path: partition() raises on all ranks or on none
             partition(n_cell_columns(cfg.params_from_values(end_time=1e9, **workloads["C5"])), world)
             aux["C5:strong"] = run_case("C5:strong", 40, 8)
-        except ValueError as e:
+        except (ValueError, RuntimeError) as e:
             aux["C5:strong"] = {"error": repr(e)}
     if rank == 0:
         out = {
@@ -403,7 +492,8 @@ def bench_main(args, rank, world, local_rank):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": head["workload"], "parallelism": head["parallelism"], "slab0": head["slab0"]},
+            "config": {"workload": head["workload"], "parallelism": head["parallelism"], "slab0": head["slab0"],
+                       "native_loop": head["native_loop"]},
             "roofline": head["roofline"], "sim": head["sim"],
         }
         if aux:

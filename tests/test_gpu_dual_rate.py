@@ -40,6 +40,11 @@ def test_dual_rate_needs_an_eligible_context(cfgmod, geom, capi):
         assert ctx.substeps() == 1
     with pytest.raises(capi.SphxError):
         _ctx(capi, prm, parts, dual_rate=9)
+    # the range check does not depend on eligibility (few lanes per particle, negative values)
+    for bad, kw in ((9, dict(lanes_per_particle=8)), (-1, dict()), (5, dict(lanes_per_particle=2))):
+        with pytest.raises(capi.SphxError) as ei:
+            _ctx(capi, prm, parts, dual_rate=bad, **kw)
+        assert ei.value.identifier == "SPHX:Ctx:dual_rate"
 
 
 def test_dual_rate_outer_step_advances_time_by_all_substeps(cfgmod, geom, capi):

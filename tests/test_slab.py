@@ -63,6 +63,12 @@ def test_slab_hip_two_ranks_half_million_particles():
     (2, 0.04, 3.0, 17, dict(rebuild_every=8, skin_h=0.05)),  # skin far too thin: the drift bound triggers the re-binnings
     (4, 0.01, 6.0, 12, dict()),
     (2, 0.005, 12.0, 7, dict()),                             # 0.25 M particles per slab: multi-block scan, 2 lanes per particle
+    # the steps as ONE replayed hipGraph (sphx_slab_graph_prepare: ten steps per replay, kernels + copies + cross-stream
+    # dependencies captured): prepared after the first call; 25 = two replays + five eager steps, and the last call finds
+    # the other state parity -> eager again
+    (2, 0.05, 3.0, 47, dict(calls=[3, 25, 19], graph_after=0)),
+    (3, 0.05, 4.5, 36, dict(calls=[4, 32], graph_after=0, rebuild_every=4)),
+    (2, 0.04, 3.0, 42, dict(calls=[2, 40], graph_after=0, rebuild_every=8, skin_h=0.05)),  # drift-triggered re-binnings inside replays
 ])
 def test_slab_native_ring_in_one_process(world, dp, DL, steps, kw):
     """The library's own step loop (sphx_slab_group_run: every slab of the ring in this process, device-to-device
@@ -79,11 +85,14 @@ def test_slab_native_ring_in_one_process(world, dp, DL, steps, kw):
     nf, nt = parts["n_fluid"], parts["n_total"]
     kw = dict(kw)
     calls = kw.pop("calls", [steps])  # the run in several calls: the ids of a re-binning in a call's last step travel with the next call
+    graph_after = kw.pop("graph_after", None)
     assert sum(calls) == steps
     engines = [slab.HipSlabEngine(prm, parts, r, world, 0, t_end=1e9, native=True, **kw) for r in range(world)]
     try:
-        for n_call in calls:
+        for k_call, n_call in enumerate(calls):
             slab.HipSlabEngine.group_run(engines, n_call)
+            if graph_after == k_call:
+                slab.HipSlabEngine.graph_prepare(engines)
         sts = [e.sync() for e in engines]
         snaps = [e.snapshot() for e in engines]
     finally:
@@ -113,6 +122,29 @@ def test_slab_native_ring_in_one_process(world, dp, DL, steps, kw):
     assert_close(drho, ref["drho_dt"][:nf], name="drho_dt", **tol)
 
 
+def _n_gpus():
+    import importlib
+    sys.path.insert(0, ROOT)
+    try:
+        return importlib.import_module("sph-poiseuille-flow_amd").capi.device_count()
+    except Exception:  # noqa: BLE001 -- no library / no driver: nothing to run on
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [(), ("--graph",)], ids=["eager", "step-graph"])
+def test_slab_native_rccl_two_ranks(extra):
+    """sphx_slab_run over a real two-rank RCCL communicator (one GPU per rank) against the single-GPU context: both messages
+    of a step go to the same peer, every rank must take the same re-binning decisions, the ids of a re-binning travel with
+    the next step.  Needs two GPUs: skipped on the one-GPU test box (there the loop runs as an in-process ring,
+    test_slab_native_ring_in_one_process, and the RCCL calls on a one-rank communicator, below)."""
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    r = _launch(2, "--engine", "hip", "--native", "--steps", "37", "--dp", "0.05", "--DL", "3.0", *extra, port=29551)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "OK" in r.stdout
+
+
 @pytest.mark.gpu
 def test_rccl_exchange_pattern_on_one_rank():
     """No second GPU on the test box (RCCL refuses two ranks on one device): the next best check of sphx_slab_run's RCCL
@@ -124,3 +156,13 @@ def test_rccl_exchange_pattern_on_one_rank():
     pkg = importlib.import_module("sph-poiseuille-flow_amd")
     pkg.capi.check(pkg.capi.lib().sphx_comm_selftest())
     pkg.capi.check(pkg.capi.lib().sphx_comm_selftest())  # (communicators come and go cleanly)
+
+
+@pytest.mark.gpu
+def test_rccl_calls_can_be_captured_into_a_graph():
+    """What sphx_slab_graph_prepare stakes the multi-GPU loop on: the grouped sends / receives and the all-reduce captured
+    into a hipGraph (two exchanges per graph) and replayed twice with fresh payloads, on a communicator of one rank."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module("sph-poiseuille-flow_amd")
+    pkg.capi.check(pkg.capi.lib().sphx_comm_selftest_graph())

@@ -1,4 +1,4 @@
-"""Fold the per-kernel counter averages of tests/profile_pmc.sh (gpurun_out/pmc_<tag>_<WL>/summary.txt) into
+"""Fold the per-kernel counter averages of tools/probes/profile_pmc.sh (gpurun_out/pmc_<tag>_<WL>/summary.txt) into
 profiles/pmc_traffic.json, which bench.py reads for roofline.traffic.
 
 HBM-side bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (both reported in KiB): the gfx950 read-side correction of

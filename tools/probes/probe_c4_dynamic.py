@@ -1,6 +1,6 @@
 """Manual probe (not a test): the full C4 run (378 700 steps) with the device-side re-bin decision forced on."""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 from types import SimpleNamespace
 prm = pkg.config.params_from_values(dp=0.005, DL=12.0, end_time=20.0, output_interval=5.0)

@@ -1,7 +1,7 @@
 """Manual probe (not a test): largest drift from the binning positions, step by step, for a start from rest
-(lattice) and for the developed start of bench.py.  python tests/probe_disp.py"""
+(lattice) and for the developed start of bench.py.  python tools/probes/probe_disp.py"""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 capi, cfg, geo = pkg.capi, pkg.config, pkg.geometry
 import bench

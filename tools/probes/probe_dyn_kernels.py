@@ -1,6 +1,6 @@
 """Manual probe (not a test): per-kernel eager times, host-driven (2) vs device-side (1) re-bin decision."""
 import json, subprocess, sys, os
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 wl = sys.argv[1] if len(sys.argv) > 1 else "C5"
 steps = sys.argv[2] if len(sys.argv) > 2 else "40"
 for d in ("2", "1"):

@@ -1,6 +1,6 @@
-"""Per-kernel graph-regime timings of one workload (manual probe): python tests/probe_kernels.py C5 [steps]"""
+"""Per-kernel graph-regime timings of one workload (manual probe): python tools/probes/probe_kernels.py C5 [steps]"""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 cfg, geo, capi = pkg.config, pkg.geometry, pkg.capi

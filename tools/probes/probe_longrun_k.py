@@ -1,7 +1,7 @@
 """L2 of the full dp = 0.025, 20 s run for several re-binning intervals (manual probe: the flow is chaotic at round-off,
-every K is another realisation).  python tests/probe_longrun_k.py 8 12 16"""
+every K is another realisation).  python tools/probes/probe_longrun_k.py 8 12 16"""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 for K in [int(a) for a in sys.argv[1:]] or [8]:
     prm = pkg.config.params_from_values(dp=0.025, DL=3.0, end_time=20.0, output_interval=1.0)

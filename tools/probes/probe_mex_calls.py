@@ -1,7 +1,7 @@
 """Manual probe (not a test): wall time of each stateless MEX-surface call at C2 (host buffers in and out)."""
 import importlib, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 mex = pkg.mex_surface
 cfg, geo = pkg.config, pkg.geometry

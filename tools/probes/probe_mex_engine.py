@@ -1,7 +1,7 @@
 """Manual probe (not a test): throughput of the unmodified six-MEX-calls-per-step loop through the stateless C ABI
 (host buffers in and out on every call: the PCIe-inclusive rate) next to the device-resident loop."""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 for name, kw, t_end in (("C2", dict(dp=0.025, DL=3.0), 0.1), ("C3", dict(dp=0.01, DL=6.0), 0.01)):
     prm = pkg.config.params_from_values(end_time=t_end, output_interval=t_end, **kw)

@@ -1,7 +1,7 @@
 """Manual probe: step time of a physical run from the lattice at rest, in windows (is the developed flow slower per step than
-the jittered analytic start bench.py times?).  python tests/probe_rate_over_time.py [dp DL t_end n_windows [dynamic_rebin]]"""
+the jittered analytic start bench.py times?).  python tools/probes/probe_rate_over_time.py [dp DL t_end n_windows [dynamic_rebin]]"""
 import importlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 dp, DL, t_end, nwin = (float(sys.argv[1]), float(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0.005, 12.0, 2.0, 10)
 dyn = int(sys.argv[5]) if len(sys.argv) > 5 else 0

@@ -1,6 +1,6 @@
 """Manual probe: libsphx's dlopen'ed RCCL beside torch.distributed's own RCCL in one process (single rank)."""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29578")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

@@ -1,7 +1,7 @@
 """Where the time of a short exact batch goes (manual probe): host time of enqueue_steps(n) and of sync(), total per
-batch for several n.  python tests/probe_short_batch.py"""
+batch for several n.  python tools/probes/probe_short_batch.py"""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 cfg, geo, capi = pkg.config, pkg.geometry, pkg.capi

@@ -2,7 +2,7 @@
 nothing?  One process, rank 0 of a 2-slab decomposition, receive buffers fixed at "0 particles".  The physics is
 meaningless (the halo empties out); the point is host time per step vs device time per step."""
 import importlib, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 slab = importlib.import_module("sph-poiseuille-flow_amd.slab")
 import torch

@@ -1,13 +1,13 @@
 """Manual probe (not a test): per-kernel device time of one x-slab step, two ranks sharing one GPU over gloo.
     SPHX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-        --master-port 29533 tests/probe_slab_kernels.py [dp DL]"""
+        --master-port 29533 tools/probes/probe_slab_kernels.py [dp DL]"""
 import ctypes as C
 import importlib
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 slab = importlib.import_module("sph-poiseuille-flow_amd.slab")
 capi, cfg, geo = pkg.capi, pkg.config, pkg.geometry

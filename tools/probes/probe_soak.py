@@ -1,7 +1,7 @@
 """Manual probe (not a test): a long stretch of the 6 M-particle case from the lattice at rest (stability of the
-rebuild schedule, graph replay and forced-rebuild handling at scale).  python tests/probe_soak.py [t_end]"""
+rebuild schedule, graph replay and forced-rebuild handling at scale).  python tools/probes/probe_soak.py [t_end]"""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("sph-poiseuille-flow_amd")
 t_end = float(sys.argv[1]) if len(sys.argv) > 1 else 0.4
 prm = pkg.config.params_from_values(dp=0.002, DL=24.0, end_time=t_end, output_interval=t_end / 4)

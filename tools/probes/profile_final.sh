@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round evidence (manual): the bench lines, rocprofv3 kernel traces of the same commands, PMC passes of the headline workload.
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"; TAG=${1:-r2}
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"; TAG=${1:-r2}
 OUT="$ROOT/gpurun_out/final_$TAG"; mkdir -p "$OUT"
 cd "$ROOT"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
@@ -12,5 +12,5 @@ for wl in C2 C4 C5; do
       --steps $st --warmup $wu --no-cpu-baseline --no-aux --profile-steps 16 > "$OUT/trace_$wl.json" 2> "$OUT/trace_$wl.err"
   f=$(find "$OUT/trace_$wl" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$wl.csv"
 done
-"$ROOT/tests/profile_pmc.sh" C2 0 200 ${TAG}f > "$OUT/pmc_c2.log" 2>&1
+"$ROOT/tools/probes/profile_pmc.sh" C2 0 200 ${TAG}f > "$OUT/pmc_c2.log" 2>&1
 head -8 "$OUT/kernel_stats_C2.csv" | cut -c1-160

@@ -2,7 +2,7 @@
 # Counter comparison of the force-pass variants (manual experiment, not a test): default | SPHX_FORCES=lds | SPHX_FORCES=pipe |
 # SPHX_NO_PIPELINE=1 (round-1 kernel).  Usage: profile_forces_variants.sh WORKLOAD STEPS
 WL=${1:-C4}; STEPS=${2:-20}
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 OUT="$ROOT/gpurun_out/pmc_forces_${WL}"
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --workload $WL --steps $STEPS --warmup 4 --no-cpu-baseline --no-aux --profile-steps 0 --dynamic 2"

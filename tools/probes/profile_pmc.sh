@@ -4,7 +4,7 @@
 # One rocprofv3 run per counter group (counters are never combined with sys/hip/hsa trace domains).
 WL=${1:-C5}; LPP=${2:-0}; STEPS=${3:-20}; TAG=${4:-r1}; EXTRA=${5:-}   # EXTRA e.g. "--dynamic 2": static schedule, so that
 # per-launch averages are not diluted by the launches that skip themselves in a dynamic context
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 OUT="$ROOT/gpurun_out/pmc_${TAG}_${WL}"
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --workload $WL --lpp $LPP --steps $STEPS --warmup 4 --no-cpu-baseline --no-aux --profile-steps 0 $EXTRA"

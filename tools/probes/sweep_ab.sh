@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of an environment switch (manual experiment): sweep_ab.sh "VAR=1" [workloads]
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"; cd "$ROOT"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"; cd "$ROOT"
 SW=$1; shift
 for wl in ${@:-C3 C4 C5}; do
   case $wl in C3) st=2000; wu=200;; C4) st=300; wu=40;; C5) st=100; wu=40;; *) st=1000; wu=100;; esac
