@@ -44,6 +44,9 @@ BYTES_PER_WALL["k_continuity_clock"] = BYTES_PER_WALL["k_continuity"]
 # small channels: pass E of a step and pass A of the next one in one launch
 BYTES_PER_FLUID["k_continuity_density"] = BYTES_PER_FLUID["k_continuity"] + BYTES_PER_FLUID["k_density"]
 BYTES_PER_WALL["k_continuity_density"] = BYTES_PER_WALL["k_continuity"] + BYTES_PER_WALL["k_density"]
+# ... and pass B of the next step as well (two launches per step)
+BYTES_PER_FLUID["k_continuity_density_kgc"] = BYTES_PER_FLUID["k_continuity_density"] + BYTES_PER_FLUID["k_kgc"]
+BYTES_PER_WALL["k_continuity_density_kgc"] = BYTES_PER_WALL["k_continuity_density"] + BYTES_PER_WALL["k_kgc"]
 STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
 
 

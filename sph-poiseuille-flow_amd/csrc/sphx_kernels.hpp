@@ -38,10 +38,6 @@
 #pragma once
 #include <type_traits>
 
-#ifndef SPHX_EXPERIMENT
-#define SPHX_EXPERIMENT 0
-#endif
-
 #include "sphx_device.hpp"
 
 namespace sphx {
@@ -142,6 +138,15 @@ struct FluidTmp {
     double *vol;     // Vol once more, 8 bytes per particle: passes B and E gather nothing else of `a`, and pulling the
                      // 32-byte records through the caches for one double costs them ~15 % (measured the other way
                      // round: 64-byte records made them 25 % slower)
+    // Large-channel kernels (LPP <= 8) keep the FLUID entries of both lists as 16-bit index differences k - i (modulo the
+    // population on a periodic grid), two rows per 32-bit word: word p of lane l = rows 2p (low half) and 2p+1 at
+    // nl_pk[p*nl_stride + l].  The neighbours of a particle lie in the three cell columns around its own: a few thousand
+    // slots either way.  Wall entries (rows behind a lane's fluid rows) stay in nl_idx / sl_idx at their row.  Halves the
+    // list bytes the passes move (at 6 M particles the lists were 40-60 % of every pass's HBM traffic).  nullptr: compact kernels.
+    int *nl_pk, *sl_pk;
+    int has_slack;     // 1: the arrays hold markedly more slots than particles (slabs), see beyond_population
+    int *sl_tot;       // [cap] entries of each particle's superset list (compact kernels with the KGC pass folded into the
+                       // fused E|A launch: volume_two_hop walks a NEIGHBOUR's superset list); nullptr: not kept
     double *seal_out;  // skinned slabs: the tail workgroup of pass E leaves {max |v|, max drift} of the owned particles here
                        // (the input of the step's max all-reduce), see slab_seal_tail
 };
@@ -299,6 +304,34 @@ constexpr int kWallBit = 1 << 30;
 __device__ __forceinline__ int list_rows(int packed) { return packed & 0xffff; }
 __device__ __forceinline__ int list_fluid_rows(int packed) { return packed >> 16; }
 
+// 16-bit entries of the large-channel lists (FluidTmp::nl_pk / sl_pk)
+constexpr int kDeltaMax = 32767;
+__device__ __forceinline__ void put_delta(int *pk, int stride, int row, int col, int d)
+{
+    reinterpret_cast<short *>(pk)[((size_t)(row >> 1) * stride + col) * 2 + (row & 1)] = (short)d;
+}
+__device__ __forceinline__ int delta_lo(int word) { return (int)(short)(word & 0xffff); }
+__device__ __forceinline__ int delta_hi(int word) { return word >> 16; }
+__device__ __forceinline__ int delta_of_row(const int *pk, int stride, int row, int col)
+{
+    const int word = pk[(size_t)(row >> 1) * stride + col];
+    return (row & 1) ? delta_hi(word) : delta_lo(word);
+}
+// index difference k - i as stored (periodic grids: the representative nearest to zero modulo the population n)
+__device__ __forceinline__ int encode_delta(int k, int i, int n, bool periodic, int *flags)
+{
+    int d = k - i;
+    if (periodic) {
+        const int half = n >> 1;
+        if (d > half) d -= n;
+        else if (d < -half) d += n;
+    }
+    if (d > kDeltaMax || d < -kDeltaMax) atomicOr(flags, 1);  // (ctx_setup keeps such grids on the compact kernels)
+    return d;
+}
+// ... and back: only wavefronts near the periodic seam can hold a particle whose neighbours wrap (see near_seam)
+__device__ __forceinline__ int wrap_index(int k, int n) { return k < 0 ? k + n : (k >= n ? k - n : k); }
+
 // Prologue shared by the passes: everything whose address does not depend on the clock is requested
 // BEFORE the run flag is looked at, so the clock read overlaps the particle's own loads.
 #define SPHX_PASS_INDEX_AT(bid, nblk)                                      \
@@ -318,10 +351,41 @@ __device__ __forceinline__ int list_fluid_rows(int packed) { return packed >> 16
 // bid / nblk: the workgroup's index among the nblk workgroups of this pass (the fused launch k_continuity_density runs the
 // pass in a sub-range of its grid).  half: also write the half-step density / pressure (needs the step's dt; the fused
 // launch runs pass A of the NEXT step, whose dt is not known yet -- pass B completes the record there).
-template <int LPP, int MODE>
+// Volume of particle k at the positions of state `s`, summed from k's OWN superset list by one lane ("two hops": the KGC
+// matrix of a particle needs its neighbours' volumes, which pass A of the same launch is still computing -- each lane
+// recomputes the one it needs; ~36 candidates).  Same kernel sum as pass A, in list order instead of the shuffle tree's.
+template <int LPP>
+__device__ __forceinline__ double volume_two_hop(const Grid &g, const Phys &ph, const FluidSet &s, const FluidTmp &t,
+                                                 const Walls &w, int k)
+{
+    const double2 pk = s.pos[k];
+    const double mk = s.mass[k];
+    const int tot = t.sl_tot[k];
+    const size_t col0 = (size_t)k * LPP;
+    double s_in = 0.0, s_ct = 0.0;
+    for (int m = 0; m < tot; ++m) {
+        const int e = t.sl_idx[(size_t)(m / LPP) * t.nl_stride + col0 + (m % LPP)];
+        const bool wall = (e & kWallBit) != 0;
+        const int j = e & (kWallBit - 1);
+        const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[j];
+        const double dx = min_image(g, pk.x - pj.x), dy = pk.y - pj.y;
+        const double r2 = dx * dx + dy * dy;
+        if (r2 > kR2Min && r2 < ph.kc.rcut2) {
+            const double W = spline_W(ph.kc, r2 * rsqrt(r2));
+            if (wall) s_ct += W * w.a[j].x;
+            else s_in += W;
+        }
+    }
+    return mk / density_from_sigma(ph.w0 + s_in, s_ct, mk, ph.rho0, ph.inv_sigma0);
+}
+
+// KGC (MODE 2 only): also the kernel-gradient-correction matrix of the particle (pass B, see k_kgc) from the same
+// candidates, the neighbours' volumes by volume_two_hop -> t.B
+template <int LPP, int MODE, bool KGC = false>
 __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                              const FluidTmp &t, const Walls &w, int bid, int nblk, bool half)
 {
+    static_assert(!KGC || MODE == 2, "the KGC pass rides on the list-walking pass A only");
     SPHX_PASS_INDEX_AT(bid, nblk);
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int ci = in_cap ? s.cell[i] : 0;
@@ -386,6 +450,7 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
     };
     constexpr bool walk = MODE == 2;
     constexpr bool record = MODE == 1;  // also write the superset list
+    double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;  // (KGC)
     if (walk) {
         const int rows = LPP == 1 ? ns : __shfl(ns, gbase);  // lane 0 of the group owns the most rows
         if (active) {
@@ -403,9 +468,19 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                         acc = true;
-                        const double W = spline_W(ph.kc, r2 * rsqrt(r2));
+                        const double inv_r = rsqrt(r2), r = r2 * inv_r;
+                        const double W = spline_W(ph.kc, r);
                         if (wall) s_ct += W * Volw;
                         else s_in += W;
+                        if (KGC) {  // the term of k_kgc for this neighbour
+                            const double Volj = wall ? Volw : volume_two_hop<LPP>(g, ph, s, t, w, k);
+                            const double ex = dx * inv_r, ey = dy * inv_r;
+                            const double fxj = spline_dW(ph.kc, r) * Volj;
+                            a11 -= dx * (fxj * ex);
+                            a12 -= dx * (fxj * ey);
+                            a21 -= dy * (fxj * ex);
+                            a22 -= dy * (fxj * ey);
+                        }
                     }
                 }
                 // wall candidates sit behind the fluid ones: the fluid count is the count reached before the first row
@@ -506,8 +581,19 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
         t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
     if (record && tid < t.nl_stride)
         t.sl_cnt[tid] = (scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0) | ((scnt_fl > sub ? (scnt_fl - sub + LPP - 1) / LPP : 0) << 16);
+    if (record && t.sl_tot && active && sub == 0) t.sl_tot[i] = scnt;
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
+    if (KGC) {
+        a11 = group_sum<LPP>(a11);
+        a12 = group_sum<LPP>(a12);
+        a21 = group_sum<LPP>(a21);
+        a22 = group_sum<LPP>(a22);
+        if (active && sub == 0) {
+            const Mat2 B = kgc_from_A(a11, a12, a21, a22);
+            t.B[i] = make_double4(B.m11, B.m12, B.m21, B.m22);
+        }
+    }
     if (active && sub == 0) {
         const double m = mass_i;
         const double rho = density_from_sigma(ph.w0 + s_in, s_ct, m, ph.rho0, ph.inv_sigma0);
@@ -607,13 +693,17 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
 // later = 1 (dual-rate loop, inner sub-steps after the first): the pressure part only -- viscous force and gravity
 // are those of the first sub-step (t.fp), there is no transport shift, the particle moves on from t.posn; pair geometry
 // stays that of the start of the outer step (s.pos), velocities are the latest ones (s.vel = the previous sub-step's).
+// open_half = 1: the {p_half, rho_half} part of the records is still open (pass A ran inside the previous step's last
+// launch, before this step's dt existed, and the KGC pass that used to close it rode in that launch too): close it on the
+// fly, for the particle and for every neighbour (one more 8-byte gather: drho), and leave rho_half in t.rho_out for pass E.
 template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
-                                                   FluidTmp t, Walls w, int later)
+                                                   FluidTmp t, Walls w, int later, int open_half)
 {
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? s.vel[i] : make_double2(0.0, 0.0);
+    const double drho_own = (open_half && in_cap) ? s.drho[i] : 0.0;
     const double4 ai = in_cap ? t.a[i] : make_double4(1.0, 0.0, 0.0, 0.0);
     const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
     const double mi = in_cap ? s.mass[i] : 1.0;
@@ -634,7 +724,9 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     const double h = ph.kc.h;
     double ax = 0.0, ay = 0.0, ix = 0.0, iy = 0.0, px = 0.0, py = 0.0, d2 = 0.0;
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
-    const double Voli = ai.x, p_i = ai.y, rhoh_i = ai.z;
+    const double Voli = ai.x;
+    double p_i = ai.y, rhoh_i = ai.z;
+    if (open_half) half_state(ph, ai.w, drho_own, dt, rhoh_i, p_i);
     const double b11i = Bi.x, b12i = Bi.y, b21i = Bi.z, b22i = Bi.w;
     int first_wall = 1 << 20;  // wall neighbours are appended behind the fluid ones: this lane's rows >= first_wall
     if (active) {
@@ -644,11 +736,14 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
             if (!(e & kWallBit)) {
                 const double2 pj = s.pos[k], vj = s.vel[k];
                 const double4 aj = t.a[k], Bj = t.B[k];
+                const double drho_j = open_half ? s.drho[k] : 0.0;
                 const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                 const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
                 const double ex = dx * inv_r, ey = dy * inv_r;
                 const double dW = spline_dW(ph.kc, r);
                 const double Volj = aj.x;
+                double p_j = aj.y, rhoh_j = aj.z;
+                if (open_half) half_state(ph, aj.w, drho_j, dt, rhoh_j, p_j);
                 const double tx = (b11i + Bj.x) * ex + (b12i + Bj.y) * ey;
                 const double ty = (b21i + Bj.z) * ex + (b22i + Bj.w) * ey;
                 const double eBe = ex * tx + ey * ty;
@@ -664,8 +759,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
                     iy -= dWVj * ty;
                 }
                 // pressure (Riemann-dissipated face pressure)
-                const double p_j = aj.y;
-                const double rho_bar = 0.5 * (rhoh_i + aj.z);
+                const double rho_bar = 0.5 * (rhoh_i + rhoh_j);
                 const double un_l = vxi * ex + vyi * ey, un_r = vxj * ex + vyj * ey;
                 const double beta = riemann_beta(un_l, un_r, ph.c_f);
                 const double p_avg = 0.5 * (p_i + p_j);
@@ -737,6 +831,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         t.veln[i] = make_double2(vxn, vyn);
         if (!later) t.fp[i] = make_double2(fpx, fpy);
         t.f[i] = make_double2(fx, fy);
+        if (open_half) t.rho_out[i] = rhoh_i;  // (pass E takes it from here and then stores the final density)
     }
     // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
 #pragma unroll
@@ -771,10 +866,11 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
 // current population has nothing to do.  Its lanes used to request their own records like everybody else before looking
 // at the clock (the latency trick of the small channels) -- on a slab, whose capacity holds 15-20 % of slack, that was
 // 15-20 % more waves going through every pass's prologue.
+// (only where there is slack -- FluidTmp::has_slack: the check is a look at the clock before anything else is requested)
 template <int LPP>
-__device__ __forceinline__ bool beyond_population(const Clock *clk, int blk)
+__device__ __forceinline__ bool beyond_population(const Clock *clk, const FluidTmp &t, int blk)
 {
-    return blk * (kBlock / LPP) >= clk->n;
+    return t.has_slack && blk * (kBlock / LPP) >= clk->n;
 }
 
 // A neighbour's x can be a period away from the particle's only if one of them was binned in the first or last cell
@@ -786,17 +882,20 @@ __device__ __forceinline__ bool near_seam(const Grid &g, double x)
     return g.periodic && (x < w || x > g.DL - w);
 }
 
-// Rows [0, rows_fl) of this lane's list column hold fluid neighbours: body(k) for each, entries three rows ahead.
+// Rows [0, rows_fl) of this lane's list column hold fluid neighbours as index differences, two rows per word (nl_pk):
+// body(i + d) for each, the words two ahead of their use (= rows 4-5 ahead).  w0 / w1: the first two words, requested by
+// the caller together with the row counts.
 template <typename Body>
-__device__ __forceinline__ void walk_fluid_rows(const FluidTmp &t, int tid, int rows_fl, int e_row0, int e_row1, Body &&body)
+__device__ __forceinline__ void walk_fluid_rows(const FluidTmp &t, int tid, int i, int rows_fl, int w0, int w1, Body &&body)
 {
     if (rows_fl <= 0) return;
-    int ea = e_row0, eb = e_row1;
-    int ec = rows_fl > 2 ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
-    for (int m = 0; m < rows_fl; ++m) {
-        const int ed = m + 3 < rows_fl ? t.nl_idx[(size_t)(m + 3) * t.nl_stride + tid] : 0;
-        body(ea);
-        ea = eb; eb = ec; ec = ed;
+    const int n_words = (rows_fl + 1) >> 1;
+    int wa = w0, wb = w1;
+    for (int p = 0; p < n_words; ++p) {
+        const int wc = p + 2 < n_words ? t.nl_pk[(size_t)(p + 2) * t.nl_stride + tid] : 0;
+        body(i + delta_lo(wa));
+        if (2 * p + 1 < rows_fl) body(i + delta_hi(wa));
+        wa = wb; wb = wc;
     }
 }
 
@@ -884,18 +983,19 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
                                                   double2 *c_pos = nullptr)
 {
     SPHX_PASS_INDEX_AT(bid, nblk);
-    if (beyond_population<LPP>(clk, blk)) return;  // (nl_cnt of lanes beyond the population is never looked at)
+    if (beyond_population<LPP>(clk, t, blk)) return;  // (nl_cnt of lanes beyond the population is never looked at)
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool lead = in_cap && sub == 0;
     const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
     const int spacked = t.sl_cnt[tid];
-    const int e_row0 = t.sl_idx[tid], e_row1 = t.sl_idx[(size_t)t.nl_stride + tid];
+    const int w_first0 = t.sl_pk[tid], w_first1 = t.sl_pk[(size_t)t.nl_stride + tid];  // rows 0-3 of the packed fluid rows
     const double dt = clk->dt;
     if (!clk->run[q]) return;
-    const bool active = i < clk->n;
+    const int n_now = clk->n;
+    const bool active = i < n_now;
     TileMap tm{0, 0, 0, 0, 0, 0};
     if (TILE > 0) {  // candidate positions of the workgroup's three-column neighbourhood staged in LDS (see tile_ranges)
-        tm = tile_ranges<LPP>(g, s, blk, clk->n, TILE);
+        tm = tile_ranges<LPP>(g, s, blk, n_now, TILE);
         for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) c_pos[sl] = s.pos[tm.index(sl)];
         __syncthreads();
     }
@@ -910,11 +1010,16 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
         return (half >> half_shift) & grp_mask;
     };
     int cnt = 0;
-    auto push = [&](bool acc, int entry) {
+    // the step's list takes the candidate's entry as it stands in the superset list: a fluid entry is the index difference to
+    // THIS particle in both, a wall entry the wall slot
+    auto push = [&](bool acc, int entry, bool wall) {
         const unsigned grp = LPP == 1 ? (acc ? 1u : 0u) : group_bits(acc);
         if (acc) {
             const int m = cnt + __popc(grp & below_me);
-            if (m / LPP < t.nl_cap) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+            if (m / LPP < t.nl_cap) {
+                if (wall) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+                else put_delta(t.nl_pk, t.nl_stride, m / LPP, row_base + (m % LPP), entry);
+            }
         }
         cnt += __popc(grp);
     };
@@ -925,52 +1030,64 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     const int rows_fl = LPP == 1 ? my_fl : __shfl(my_fl, gbase + LPP - 1);
     const double xi = pi.x, yi = pi.y;
     double s_in = 0.0, s_ct = 0.0;
-    // Three rows per turn.  A row is entry -> position -> test: the entries run six rows ahead (two turns), the positions three
-    // (each requested into the register whose value has just been used -- a rotating buffer would make every turn wait for
-    // the newest request); requests past the last row repeat it: no branch around the loads, the values are not used.
+    // Three rows per turn.  A row is entry -> position -> test: the entries (16-bit index differences, two rows per word) run
+    // ahead by whole words, the positions three rows (each requested into the register whose value has just been used -- a
+    // rotating buffer would make every turn wait for the newest request); requests past the last row repeat it: no branch
+    // around the loads, the values are not used.
     auto fluid_rows = [&](auto fold) {
         if (rows_fl <= 0) return;
         const int last = rows_fl - 1;
-        auto entry = [&](int m) { return t.sl_idx[(size_t)min(m, last) * t.nl_stride + tid]; };
-        auto row = [&](int e, const double2 &pj) {
+        constexpr bool kFold = decltype(fold)::value;
+        auto word = [&](int p) { return t.sl_pk[(size_t)min(p, last >> 1) * t.nl_stride + tid]; };
+        auto index = [&](int d) { return kFold ? wrap_index(i + d, n_now) : i + d; };
+        auto row = [&](int d, const double2 &pj) {
             double dx = xi - pj.x;
-            if (decltype(fold)::value) dx = min_image(g, dx);
+            if (kFold) dx = min_image(g, dx);
             const double dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy;
             const bool acc = r2 > kR2Min && r2 < ph.kc.rcut2;
             const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));  // (NaN for a coincident pair: discarded by the select)
             s_in += acc ? W : 0.0;
-            push(acc, e);
+            push(acc, d, false);
         };
-        int ea = e_row0, eb = rows_fl > 1 ? e_row1 : e_row0, ec = entry(2);
-        int ed = entry(3), ee = entry(4), ef = entry(5);
+        // words: [wa wb] hold rows m .. m+3 of the current turn and the next, [wc wd] the four behind them
+        int wa = w_first0, wb = w_first1, wc = word(2), wd = word(3);
         if (TILE > 0) {  // positions from the tile (a few cycles away): only the entries run ahead
             auto fetch = [&](int k) -> double2 {  // (early return, not if/else: see k_kgc_w)
                 const int slot = tm.slot(k);
                 if (slot >= 0) return c_pos[slot];
                 return s.pos[k];
             };
-            for (int m = 0; m < rows_fl; m += 3) {
-                const int eg = entry(m + 6), eh = entry(m + 7), ei = entry(m + 8);
-                row(ea, fetch(ea));
-                if (m + 1 < rows_fl) row(eb, fetch(eb));
-                if (m + 2 < rows_fl) row(ec, fetch(ec));
-                ea = ed; eb = ee; ec = ef;
-                ed = eg; ee = eh; ef = ei;
+            for (int m = 0; m < rows_fl; m += 4) {
+                const int we = word((m >> 1) + 4), wf = word((m >> 1) + 5);
+                const int d0 = delta_lo(wa), d1 = delta_hi(wa), d2 = delta_lo(wb), d3 = delta_hi(wb);
+                row(d0, fetch(index(d0)));
+                if (m + 1 < rows_fl) row(d1, fetch(index(d1)));
+                if (m + 2 < rows_fl) row(d2, fetch(index(d2)));
+                if (m + 3 < rows_fl) row(d3, fetch(index(d3)));
+                wa = wc; wb = wd; wc = we; wd = wf;
             }
             return;
         }
-        double2 pa = s.pos[ea], pb = s.pos[eb], pc = s.pos[ec];
-        for (int m = 0; m < rows_fl; m += 3) {
-            const int eg = entry(m + 6), eh = entry(m + 7), ei = entry(m + 8);
-            row(ea, pa);
-            pa = s.pos[ed];
-            if (m + 1 < rows_fl) row(eb, pb);
-            pb = s.pos[ee];
-            if (m + 2 < rows_fl) row(ec, pc);
-            pc = s.pos[ef];
-            ea = ed; eb = ee; ec = ef;
-            ed = eg; ee = eh; ef = ei;
+        // four rows per turn, their positions requested one turn ahead.  Requests past the last row decode whatever the word
+        // holds -- an index difference some earlier list left there: a slot of the arrays, clamped to be sure -- so there
+        // is no branch and no select around the loads; the values are not used.
+        auto ahead = [&](int d) { return kFold ? wrap_index(i + d, n_now) : max(0, min(i + d, t.cap - 1)); };
+        int d0 = delta_lo(wa), d1 = delta_hi(wa), d2 = delta_lo(wb), d3 = delta_hi(wb);
+        double2 p0 = s.pos[index(d0)], p1 = s.pos[ahead(d1)], p2 = s.pos[ahead(d2)], p3 = s.pos[ahead(d3)];
+        for (int m = 0; m < rows_fl; m += 4) {
+            const int we = word((m >> 1) + 4), wf = word((m >> 1) + 5);
+            const int n0 = delta_lo(wc), n1 = delta_hi(wc), n2 = delta_lo(wd), n3 = delta_hi(wd);
+            row(d0, p0);
+            p0 = s.pos[ahead(n0)];
+            if (m + 1 < rows_fl) row(d1, p1);
+            p1 = s.pos[ahead(n1)];
+            if (m + 2 < rows_fl) row(d2, p2);
+            p2 = s.pos[ahead(n2)];
+            if (m + 3 < rows_fl) row(d3, p3);
+            p3 = s.pos[ahead(n3)];
+            d0 = n0; d1 = n1; d2 = n2; d3 = n3;
+            wa = wc; wb = wd; wc = we; wd = wf;
         }
     };
     if (__any(active && near_seam(g, xi))) fluid_rows(std::true_type{});
@@ -980,21 +1097,26 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
         bool acc = false, wall = false;
         int e = 0;
         if (m < ns) {
-            e = t.sl_idx[(size_t)m * t.nl_stride + tid];
-            wall = (e & kWallBit) != 0;
-            const int k = e & (kWallBit - 1);
-            const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
+            wall = m >= my_fl;  // a lane's fluid rows come first
+            double2 pj;
+            if (wall) {
+                e = t.sl_idx[(size_t)m * t.nl_stride + tid];
+                pj = w.pos[e & (kWallBit - 1)];
+            } else {
+                e = delta_of_row(t.sl_pk, t.nl_stride, m, tid);
+                pj = s.pos[wrap_index(i + e, n_now)];
+            }
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy;
             if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                 acc = true;
                 const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
-                if (wall) s_ct += W * w.a[k].x;
+                if (wall) s_ct += W * w.a[e & (kWallBit - 1)].x;
                 else s_in += W;
             }
         }
         cnt_fl += LPP == 1 ? ((acc && !wall) ? 1 : 0) : __popc(group_bits(acc && !wall));
-        push(acc, e);
+        push(acc, e, wall);
     }
     if (active && cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
     cnt_fl = min(cnt_fl, cnt);
@@ -1023,14 +1145,15 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
 {
     static_assert(MODE == 0 || MODE == 1, "sweeping forms only");
     SPHX_PASS_INDEX_AT(bid, nblk);
-    if (beyond_population<LPP>(clk, blk)) return;
+    if (beyond_population<LPP>(clk, t, blk)) return;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int ci = in_cap ? s.cell[i] : 0;
     const bool lead = in_cap && sub == 0;
     const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
     const double dt = clk->dt;
     if (!clk->run[q]) return;
-    const bool active = i < clk->n;
+    const int n_now = clk->n;
+    const bool active = i < n_now;
     constexpr bool record = MODE == 1;
     double s_in = 0.0, s_ct = 0.0;
     int cnt = 0, scnt = 0;
@@ -1044,11 +1167,15 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
         const unsigned half_ = lane < 32 ? (unsigned)bal : (unsigned)(bal >> 32);
         return (half_ >> half_shift) & grp_mask;
     };
-    auto push_to = [&](int *idx, int cap, int &n, bool acc, int entry) {
+    // fluid entries go to the packed list as index differences to this group's particle, wall entries to the 32-bit one
+    auto push_to = [&](int *idx, int *pk, int cap, int &n, bool acc, int entry, bool wall) {
         const unsigned grp = LPP == 1 ? (acc ? 1u : 0u) : group_bits(acc);
         if (acc) {
             const int m = n + __popc(grp & below_me);
-            if (m / LPP < cap) idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+            if (m / LPP < cap) {
+                if (wall) idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
+                else put_delta(pk, t.nl_stride, m / LPP, row_base + (m % LPP), entry);
+            }
         }
         n += __popc(grp);
     };
@@ -1138,8 +1265,9 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
                 const bool acc = has && r2 < ph.kc.rcut2;
                 const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
                 s_in += acc ? W : 0.0;
-                push_to(t.nl_idx, t.nl_cap, cnt, acc, k);
-                if (record) push_to(t.sl_idx, t.sl_cap, scnt, has, k);
+                const int d = has ? encode_delta(k, i, n_now, g.periodic != 0, t.flags) : 0;
+                push_to(t.nl_idx, t.nl_pk, t.nl_cap, cnt, acc, d, false);
+                if (record) push_to(t.sl_idx, t.sl_pk, t.sl_cap, scnt, has, d, false);
                 has = has_n; k = k_n; pj = pj_n;
             }
         }
@@ -1165,8 +1293,8 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
                 const bool acc = in && r2 < ph.kc.rcut2;
                 const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
                 s_ct += acc ? W * va : 0.0;
-                push_to(t.nl_idx, t.nl_cap, cnt, acc, ka | kWallBit);
-                if (record) push_to(t.sl_idx, t.sl_cap, scnt, in && r2 < t.sl_rcut2, ka | kWallBit);
+                push_to(t.nl_idx, t.nl_pk, t.nl_cap, cnt, acc, ka | kWallBit, true);
+                if (record) push_to(t.sl_idx, t.sl_pk, t.sl_cap, scnt, in && r2 < t.sl_rcut2, ka | kWallBit, true);
                 ka = kb; pa = pb; va = vb_;
             }
         }
@@ -1191,12 +1319,15 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
     }
 }
 
+// n_tiles: workgroup-sized tiles of the pass; the grid may be smaller (grid-stride over the tiles: the conditional launches
+// of a dynamic context, which are idle most of the time, see launch_physics)
 template <int LPP, int MODE>
 __global__ __launch_bounds__(kBlock) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
-                                                            FluidTmp t, Walls w, int cond_fresh)
+                                                            FluidTmp t, Walls w, int cond_fresh, int n_tiles)
 {
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
-    density_sweep_body_w<LPP, MODE>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true);
+    for (int b = (int)blockIdx.x; b < n_tiles; b += (int)gridDim.x)
+        density_sweep_body_w<LPP, MODE>(clk, q, g, ph, s, t, w, b, n_tiles, true);
 }
 
 template <int LPP, int TILE = 0>
@@ -1218,13 +1349,13 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     __shared__ double2 c_pos[kSlots];
     __shared__ double c_vol[kSlots];
     SPHX_PASS_INDEX();
-    if (beyond_population<LPP>(clk, blk)) return;
+    if (beyond_population<LPP>(clk, t, blk)) return;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool closes = finish_half && in_cap && sub == 0;  // (see k_kgc)
     const double4 a_own = closes ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
     const double drho_own = closes ? s.drho[i] : 0.0;
     const int packed = t.nl_cnt[tid];
-    const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
+    const int w0 = t.nl_pk[tid], w1 = t.nl_pk[(size_t)t.nl_stride + tid];
     if (!clk->run[q]) return;
     const int n_now = clk->n;
     const bool active = i < n_now;
@@ -1250,9 +1381,6 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     const double xi = pi.x, yi = pi.y;
     double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;
     auto term = [&](double dx, double dy, double Volj) {
-#if SPHX_EXPERIMENT == 1   /* memory only */
-        a11 += dx; a12 += dy; a21 += Volj;
-#else
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
         const double ex = dx * inv_r, ey = dy * inv_r;
         const double fxj = spline_dW_sel(ph.kc, r) * Volj;
@@ -1260,32 +1388,19 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
         a12 -= dx * (fxj * ey);
         a21 -= dy * (fxj * ex);
         a22 -= dy * (fxj * ey);
-#endif
     };
-#if SPHX_EXPERIMENT == 2   /* compute only: no gathers */
-    walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
-        term(xi - (double)(k & 7) * 1e-3 - 1e-4, yi - (double)(k & 3) * 1e-3, 1e-5);
-    });
-#elif SPHX_EXPERIMENT == 3   /* gathers only, list entries synthetic: neighbours i-8..i+8 */
-    for (int m = 0; m < rows_fl; ++m) {
-        const int k = max(0, min(t.cap - 1, i + (m * LPP + sub) - 10));
-        const double2 pj = s.pos[k];
-        term(xi - pj.x + 1e-4, yi - pj.y, t.vol[k]);
-    }
-#else
     if (__any(active && near_seam(g, xi)))
-        walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+        walk_fluid_rows(t, tid, i, rows_fl, w0, w1, [&](int k) {
             double2 pj; double Volj;
-            fetch(k, pj, Volj);
+            fetch(wrap_index(k, n_now), pj, Volj);
             term(min_image(g, xi - pj.x), yi - pj.y, Volj);
         });
     else
-        walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+        walk_fluid_rows(t, tid, i, rows_fl, w0, w1, [&](int k) {
             double2 pj; double Volj;
             fetch(k, pj, Volj);
             term(xi - pj.x, yi - pj.y, Volj);
         });
-#endif
     walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
         const double2 pj = w.pos[k];
         term(min_image(g, xi - pj.x), yi - pj.y, w.a[k].x);
@@ -1319,7 +1434,7 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
     __shared__ double4 c_a[kSlots], c_B[kSlots];
     SPHX_PASS_INDEX();
-    if (beyond_population<LPP>(clk, blk)) {  // (a slab's arrays have 15-20 % of slack: see beyond_population)
+    if (beyond_population<LPP>(clk, t, blk)) {  // (a slab's arrays have 15-20 % of slack: see beyond_population)
         if (threadIdx.x == 0 && clk->run[q]) t.dpart[blk] = 0.0;
         return;
     }
@@ -1329,7 +1444,7 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
     const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
     const double mi = in_cap ? s.mass[i] : 1.0;
     const int packed = t.nl_cnt[tid];
-    const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
+    const int w0 = t.nl_pk[tid], w1 = t.nl_pk[(size_t)t.nl_stride + tid];
     const bool tracked = s.posb != nullptr;
     const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
     const double dt = clk->dt;
@@ -1368,10 +1483,6 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
         return n;
     };
     auto fluid_pair = [&](const FluidNb &n, double dx) {
-#if SPHX_EXPERIMENT == 1   /* memory only */
-        ax += dx + n.p.y; ay += n.v.x + n.v.y; ix += n.a.x + n.a.y; iy += n.a.z; px += n.B.x + n.B.y; py += n.B.z + n.B.w;
-        return;
-#endif
         const double dy = yi - n.p.y;
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
         const double ex = dx * inv_r, ey = dy * inv_r;
@@ -1396,25 +1507,16 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
         px -= (p_face * tx) * dWVj;
         py -= (p_face * ty) * dWVj;
     };
-#if SPHX_EXPERIMENT == 2   /* compute only: no gathers */
-    walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
-        FluidNb n;
-        n.p = make_double2(xi - (double)(k & 7) * 1e-3 - 1e-4, yi - (double)(k & 3) * 1e-3);
-        n.v = make_double2(vxi * 0.9, vyi + 0.01); n.a = ai; n.B = Bi;
-        fluid_pair(n, xi - n.p.x);
-    });
-#else
     if (__any(active && near_seam(g, xi)))
-        walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
-            const FluidNb n = fetch(k);
+        walk_fluid_rows(t, tid, i, rows_fl, w0, w1, [&](int k) {
+            const FluidNb n = fetch(wrap_index(k, n_now));
             fluid_pair(n, min_image(g, xi - n.p.x));
         });
     else
-        walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+        walk_fluid_rows(t, tid, i, rows_fl, w0, w1, [&](int k) {
             const FluidNb n = fetch(k);
             fluid_pair(n, xi - n.p.x);
         });
-#endif
     // wall neighbours: viscous and transport now, pressure once force_prior is complete (p_wall needs it, :931-934)
     walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
         const double2 pj = w.pos[k];
@@ -1662,13 +1764,13 @@ __device__ __forceinline__ void slab_seal_tail(const Clock *clk, int q, const Fl
 template <int LPP, bool WALK, int TILE>
 __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                                 const FluidTmp &t, const Walls &w, int do_hist, int tail, int bid, int nb,
-                                                double2 *c_pos, double2 *c_vel, double *c_vol, int next_half = 0)
+                                                double2 *c_pos, double2 *c_vel, double *c_vol, int next_half = 0, int open_half = 0)
 {
     const int blk = xcd_block(bid, nb);
     const int tid = blk * kBlock + threadIdx.x;
     const int i = tid / LPP, sub = tid % LPP;
     const bool in_cap = i < t.cap;
-    if (WALK && beyond_population<LPP>(clk, blk)) {  // nothing here: only the workgroup's entry of the max |v|^2 reduction is owed
+    if (WALK && beyond_population<LPP>(clk, t, blk)) {  // nothing here: only the workgroup's entry of the max |v|^2 reduction is owed
         if (threadIdx.x == 0 && clk->run[q] && !next_half) {
             if (tail) __hip_atomic_store(reinterpret_cast<unsigned long long *>(&t.vpart[blk]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else t.vpart[blk] = 0.0;
@@ -1681,24 +1783,28 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const int nn_all = list_rows(packed);
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
     // two): count -> entry -> neighbour data becomes {count, entries} -> neighbour data
-    const int e_row0 = t.nl_idx[tid], e_row1 = t.nl_idx[(size_t)t.nl_stride + tid];
+    // (WALK: the first two words of the packed fluid rows, see FluidTmp::nl_pk)
+    const int *first_rows = WALK ? t.nl_pk : t.nl_idx;
+    const int e_row0 = first_rows[tid], e_row1 = first_rows[(size_t)t.nl_stride + tid];
     // (rows 2 and 3 only where lanes own that many: few lanes per particle)
     const int e_row2 = (!WALK && LPP <= 8) ? t.nl_idx[2 * (size_t)t.nl_stride + tid] : 0;
     const int e_row3 = (!WALK && LPP <= 8) ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     const bool lead = in_cap && sub == 0;
     const double4 a_own = lead ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
-    const double rhoh_i = a_own.z;
+    // (open_half: the record's half-step part was never closed -- pass CD computed rho_half and left it in rho_out)
+    const double rhoh_i = (open_half && lead) ? t.rho_out[i] : a_own.z;
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
     const double dt = clk->dt;
     if (!clk->run[q]) return;
-    const bool active = i < clk->n;
+    const int n_now = clk->n;
+    const bool active = i < n_now;
     double rate = 0.0, v2 = 0.0;
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
     if (WALK) {
         const int rows = active ? nn_all : 0, rows_fl = active ? list_fluid_rows(packed) : 0;
         TileMap tm{0, 0, 0, 0, 0, 0};
         if (TILE > 0) {
-            tm = tile_ranges<LPP>(g, s, blk, clk->n, TILE);
+            tm = tile_ranges<LPP>(g, s, blk, n_now, TILE);
             for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
                 const int k = tm.index(sl);
                 c_pos[sl] = s.pos[k];
@@ -1720,13 +1826,13 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
             rate += ((vxi - ujx) * ex + (vyi - ujy) * ey) * spline_dW_sel(ph.kc, r) * Volj;
         };
         if (__any(active && near_seam(g, xi)))
-            walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+            walk_fluid_rows(t, tid, i, rows_fl, e_row0, e_row1, [&](int k) {
                 double2 pj, vj; double Volj;
-                fetch(k, pj, vj, Volj);
+                fetch(wrap_index(k, n_now), pj, vj, Volj);
                 term(min_image(g, xi - pj.x), yi - pj.y, vj.x, vj.y, Volj);
             });
         else
-            walk_fluid_rows(t, tid, rows_fl, e_row0, e_row1, [&](int k) {
+            walk_fluid_rows(t, tid, i, rows_fl, e_row0, e_row1, [&](int k) {
                 double2 pj, vj; double Volj;
                 fetch(k, pj, vj, Volj);
                 term(xi - pj.x, yi - pj.y, vj.x, vj.y, Volj);
@@ -1805,7 +1911,8 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
 
 template <int LPP, bool WALK, int TILE>
 __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
-                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half)
+                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half,
+                                                       int open_half)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
@@ -1816,7 +1923,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
         else continuity_tail(clk, q, ph, t, nb);
         return;
     }
-    continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol, next_half);
+    continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol, next_half, open_half);
 }
 
 // Small channels, steps that do not re-bin: pass E of this step and pass A of the NEXT step in one launch, side by
@@ -1826,9 +1933,13 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
 // on the new state s_next, walking the superset list, into the other list / record buffers (t_next) -- without the
 // half-step density and pressure, which need the next step's dt (the tail workgroup of this very launch computes it):
 // pass B of the next step closes that (k_kgc, finish_half); workgroup 2 nb: the clock (continuity_tail).
-template <int LPP>
+// KGC: pass B of the next step rides along as well (density_body<.., KGC>, volume_two_hop) -- a step is then TWO launches,
+// pass CD and this one; pass CD closes the half-step records itself (k_forces, open_half), which is what open_half says
+// about the step pass E belongs to here.
+template <int LPP, bool KGC>
 __global__ __launch_bounds__(kBlock) void k_continuity_density(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
-                                                               Walls w, FluidSet s_next, FluidTmp t_next, int with_tail)
+                                                               Walls w, FluidSet s_next, FluidTmp t_next, int with_tail,
+                                                               int open_half)
 {
     const int nb = ((int)gridDim.x - with_tail) / 2;  // (with_tail = 0: kernel timing, the clock must not advance)
     const int b = (int)blockIdx.x;
@@ -1836,8 +1947,8 @@ __global__ __launch_bounds__(kBlock) void k_continuity_density(Clock *clk, int q
         continuity_tail(clk, q, ph, t, nb);
         return;
     }
-    if (b < nb) continuity_body<LPP, false, 0>(clk, q, g, ph, s, t, w, 0, with_tail, b, nb, nullptr, nullptr, nullptr);
-    else density_body<LPP, 2>(clk, q, g, ph, s_next, t_next, w, b - nb, nb, false);
+    if (b < nb) continuity_body<LPP, false, 0>(clk, q, g, ph, s, t, w, 0, with_tail, b, nb, nullptr, nullptr, nullptr, 0, open_half);
+    else density_body<LPP, 2, KGC>(clk, q, g, ph, s_next, t_next, w, b - nb, nb, false);
 }
 
 // the same with the large-channel forms of the two passes (mid-size channels: 4-8 lanes per particle, clock in the tail)

@@ -24,7 +24,7 @@ struct KernelTimer {
     struct Pending { int idx; hipEvent_t a, b; };
     std::vector<Pending> pending;     // eager launches: one-shot events
     std::vector<Pending> graph_evs;   // events recorded by nodes of the profiling graph (re-armed per replay)
-    bool warned = false;
+    bool warned = false, timer_log = false;  // (timer_log: SPHX_DEBUG_SWITCHES=log)
     int index_of(const char *name)
     {
         for (size_t k = 0; k < names.size(); ++k) if (names[k] == name) return (int)k;
@@ -38,7 +38,7 @@ struct KernelTimer {
         if (e == hipSuccess) { total_ms[idx] += ms; launches[idx] += 1; }
         else {
             (void)hipGetLastError();
-            if (getenv("SPHX_DEBUG") && !warned) { warned = true; fprintf(stderr, "sphx: hipEventElapsedTime: %s\n", hipGetErrorString(e)); }
+            if (timer_log && !warned) { warned = true; fprintf(stderr, "sphx: hipEventElapsedTime: %s\n", hipGetErrorString(e)); }
         }
     }
     void collect()
@@ -103,6 +103,7 @@ struct sphx_ctx {
     DevBuf<double> drhon, rho_out, p_out, vpart, dpart, vtile, fvol;
     int n_vtiles = 0;            // > 0: k_max_tiles folds the per-block maxima first (very many blocks)
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, sl_idx, sl_cnt, flags, tile;
+    DevBuf<int> nl_pk, sl_pk, nl_pk2;  // large-channel kernels: fluid entries as 16-bit index differences (FluidTmp::nl_pk)
     DevBuf<double2> wpos;
     DevBuf<double4> wa;
     DevBuf<int> wid, wstart, wrow_any;
@@ -143,8 +144,6 @@ struct sphx_ctx {
     DevBuf<int> kid, counters, n_new, ticket;  // (ticket: see last_workgroup_out)
     SlabPack pack{};
     int64_t slab_steps_enqueued = 0, slab_step0 = 0;
-    // optional (SPHX_SLAB_GRAPH=1): each half-step captured once per parity (and per buffer set) and replayed;
-    // slower than plain launches for graphs this small, see slab_half
     // native step loop (sphx_slab_run / sphx_slab_group_run): library-owned message buffers, RCCL communicator
     DevBuf<double> msg_sl, msg_sr, msg_rl, msg_rr, vmax_l, vmax_g;  // (vmax_*: {max |v|, max drift})
     // skinned slabs (re-binning every K-th step): the exchange lists of the cycle, see SlabLists
@@ -160,8 +159,6 @@ struct sphx_ctx {
     std::vector<const sphx_ctx *> steps_graph_ring;  // the contexts the graph was captured for
     int steps_graph_cur = 0;                          // ... and the state parity it starts from
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipGraphExec_t slab_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [half][parity]
-    const void *slab_key[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
     // Dynamic re-binning (large channels): the device decides when to re-bin, every step carries the (self-skipping)
     // re-binning kernels, the layout is rebuilt in place -> lay stays 0, only the state parity alternates
@@ -170,6 +167,12 @@ struct sphx_ctx {
     // (k_continuity_density).  The neighbour list and the {Vol, p, rho_h, rho} records then exist once per state parity:
     // tmp_par[p] is `tmp` with the buffers of parity p; out_par = the parity of the last executed step (its Vol).
     bool fuse_ea = false;
+    // ... and pass B of the next step rides in that launch too (density_body<.., KGC>, volume_two_hop): a step that does not
+    // re-bin is TWO launches, pass CD (which closes the half-step records itself: open_half) and E | A | B + clock.  The
+    // KGC matrices then exist once per state parity like the records (fB2).
+    bool fuse_eab = false;
+    DevBuf<int> sl_tot;
+    DevBuf<double4> fB2;
     bool lds_tiles_a = false;    // pass A's walk gathers the candidate positions from an LDS tile
     bool sweep_kernels = false;  // pass A's cell sweep in its large-channel form (k_density_sweep_w)
     int n_in = 1;                // dual-rate loop: inner sub-steps per step slot (1 = the reference's single-rate loop)
@@ -206,7 +209,6 @@ struct sphx_ctx {
     {
         if (stream) (void)hipStreamSynchronize(stream);  // the buffers go back to the pool: nothing may still use them
         drop_graph();
-        for (auto &h : slab_graph) for (auto &e : h) if (e) (void)hipGraphExecDestroy(e);
         if (steps_graph) (void)hipGraphExecDestroy(steps_graph);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -221,6 +223,31 @@ struct sphx_ctx {
 };
 
 namespace {
+
+// A/B switches for measurements, all behind ONE environment variable read once per process:
+//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_fuse_kgc,no_lds_tiles,log
+// (no_tail_clock: the clock update as a launch of its own on every step; no_fuse_ea: passes E and A in separate launches;
+//  no_fuse_kgc: pass B as a launch of its own (three launches per step on small channels);
+//  no_lds_tiles: large-channel passes gather from global memory; log: forced re-binnings and timer problems on stderr)
+struct DebugSwitches {
+    bool no_tail_clock = false, no_fuse_ea = false, no_fuse_kgc = false, no_lds_tiles = false, log = false;
+};
+const DebugSwitches &debug_switches()
+{
+    static const DebugSwitches sw = [] {
+        DebugSwitches d;
+        const char *e = std::getenv("SPHX_DEBUG_SWITCHES");
+        const std::string v = e ? e : "";
+        auto has = [&](const char *name) { return ("," + v + ",").find(std::string(",") + name + ",") != std::string::npos; };
+        d.no_tail_clock = has("no_tail_clock");
+        d.no_fuse_ea = has("no_fuse_ea");
+        d.no_fuse_kgc = has("no_fuse_kgc");
+        d.no_lds_tiles = has("no_lds_tiles");
+        d.log = has("log");
+        return d;
+    }();
+    return sw;
+}
 
 thread_local sphx_ctx *g_search_ctx = nullptr;  // owns the temporary context of sphx_neighbor_search until fetch
 thread_local sphx_ctx *g_fetch_src = nullptr;   // context whose pair list the next sphx_neighbor_fetch copies out
@@ -291,46 +318,51 @@ int dual_rate_substeps(const sphx_params &prm)
 // inner (dual-rate loop, compact kernels only): this launch of pass CD / E belongs to an inner sub-step -- CD does the
 //        pressure part only, E hands the next sub-step its half-step density
 template <int LPP>
-void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode, int tail, int inner)
+void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode, int tail, int inner, int open_half)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
-    if (!only || only == 1) {
-        bool walk_w = false, sweep_w = false;  // large channels (few lanes per particle): the "_w" forms, see sphx_kernels.hpp
-        if constexpr (LPP <= 8) { walk_w = c->walk_kernels; sweep_w = c->sweep_kernels; }
-        // the cell sweep: mode 0 writes the step's list, mode 1 the superset list as well
-        auto sweep = [&](const char *name, auto mode, int cond) {
-            constexpr int M = decltype(mode)::value;
-            if (!sweep_w) launch(c, name, k_density<LPP, M>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
-            else if constexpr (LPP <= 8) launch(c, name, k_density_sweep_w<LPP, M>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
-        };
-        if (dmode == 0) sweep("k_density", std::integral_constant<int, 0>{}, -1);
-        else if (dmode == 1) sweep("k_density_build", std::integral_constant<int, 1>{}, -1);
-        else {
-            // dmode 2: walk the superset list; 3 (dynamic contexts): build and walk, each skipping itself according to the
-            // clock's `fresh`
-            const int cond = dmode == 2 ? -1 : 0;
-            if (dmode == 3) sweep("k_density_build", std::integral_constant<int, 1>{}, 1);
-            if (!walk_w) launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
-            else if constexpr (LPP <= 8) {
-                if (c->lds_tiles_a) launch(c, "k_density_walk", k_density_w<LPP, tile_slots(LPP)>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
-                else launch(c, "k_density_walk", k_density_w<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
-            }
-        }
-    }
-    // large channels (few lanes per particle) run the "_w" forms of passes B, CD and E, see sphx_kernels.hpp
-    bool walk = false;
-    if constexpr (LPP <= 8) walk = c->walk_kernels;
     const dim3 ge(c->n_blocks_particles + (tail ? 1 : 0));  // tail: 1 = clock, 2 = a slab's local maxima (slab_seal_tail)
     const char *name_e = tail ? "k_continuity_clock" : "k_continuity";
-    if (!walk) {
+    if constexpr (LPP >= 16) {
+        // small channels: the compact kernels (32-bit lists)
+        if (!only || only == 1) {
+            if (dmode == 0) launch(c, "k_density", k_density<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
+            else if (dmode == 1) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, -1);
+            else {
+                // dmode 2: walk the superset list; 3 (dynamic contexts): build and walk, each skipping itself according to the
+                // clock's `fresh`
+                const int cond = dmode == 2 ? -1 : 0;
+                if (dmode == 3) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, 1);
+                launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+            }
+        }
         if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
-        if (!only || only == 3) launch(c, inner ? "k_forces_inner" : "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, inner);
+        if (!only || only == 3) launch(c, inner ? "k_forces_inner" : "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, inner, open_half);
         if (!only || only == 4)
-            launch(c, inner ? "k_continuity_inner" : name_e, k_continuity<LPP, false, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, inner);
-    } else if constexpr (LPP <= 8) {
-        // LDS tiles (tile_ranges): the force pass always; KGC and continuity where measured to pay (lds_tiles_be)
+            launch(c, inner ? "k_continuity_inner" : name_e, k_continuity<LPP, false, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, inner, open_half);
+    } else {
+        // large channels (few lanes per particle): the "_w" forms, see sphx_kernels.hpp -- fluid list entries are 16-bit index
+        // differences, so builders and walkers always go together
         constexpr int T = tile_slots(LPP);
+        if (!only || only == 1) {
+            auto sweep = [&](const char *name, auto mode, int cond) {  // the cell sweep: mode 0 writes the step's list, mode 1 the superset list as well
+                constexpr int M = decltype(mode)::value;
+                // the build variant of a dynamic context is idle on four steps out of five: a grid-stride launch of an eighth
+                // of the workgroups costs an eighth to skip (6 M particles: 47 k idle workgroups were ~70 us of every step)
+                const unsigned nb = cond >= 0 ? std::max<unsigned>(1u, (unsigned)c->n_blocks_particles / 8u) : (unsigned)c->n_blocks_particles;
+                launch(c, name, k_density_sweep_w<LPP, M>, dim3(nb), bp, clk, q, c->grid, c->phys, s, t, c->walls, cond, c->n_blocks_particles);
+            };
+            if (dmode == 0) sweep("k_density", std::integral_constant<int, 0>{}, -1);
+            else if (dmode == 1) sweep("k_density_build", std::integral_constant<int, 1>{}, -1);
+            else {
+                const int cond = dmode == 2 ? -1 : 0;
+                if (dmode == 3) sweep("k_density_build", std::integral_constant<int, 1>{}, 1);
+                if (c->lds_tiles_a) launch(c, "k_density_walk", k_density_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+                else launch(c, "k_density_walk", k_density_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+            }
+        }
+        // LDS tiles (tile_ranges): the force pass always; KGC and continuity where measured to pay (lds_tiles_be)
         if (!only || only == 2) {
             if (c->lds_tiles_be) launch(c, "k_kgc", k_kgc_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
             else launch(c, "k_kgc", k_kgc_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
@@ -340,22 +372,23 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             else launch(c, "k_forces", k_forces_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
         }
         if (!only || only == 4) {
-            if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
-            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
+            if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0, 0);
+            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0, 0);
         }
     }
 }
 
+// open_half: passes CD / E of a step whose half-step records were never closed (see sphx_ctx::fuse_eab)
 void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0, int dmode = 0,
-                        int tail = 0, int inner = 0)
+                        int tail = 0, int inner = 0, int open_half = 0)
 {
     switch (c->lpp) {
-        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
-        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
-        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
-        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
-        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
-        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
+        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
+        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
+        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
+        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
+        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
         default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
     }
 }
@@ -387,10 +420,16 @@ void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderA
 }
 
 template <int LPP>
-void launch_fused_ea_t(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail)
+void launch_fused_ea_t(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail,
+                       int open_half)
 {
-    launch(c, "k_continuity_density", k_continuity_density<LPP>, dim3(2 * c->n_blocks_particles + tail), dim3(kBlock),
-           c->clock.get(), q, c->grid, c->phys, s, t, c->walls, sn, tn, tail);
+    const dim3 grid(2 * c->n_blocks_particles + tail), block(kBlock);
+    if (c->fuse_eab)
+        launch(c, "k_continuity_density_kgc", k_continuity_density<LPP, true>, grid, block, c->clock.get(), q, c->grid, c->phys, s, t,
+               c->walls, sn, tn, tail, open_half);
+    else
+        launch(c, "k_continuity_density", k_continuity_density<LPP, false>, grid, block, c->clock.get(), q, c->grid, c->phys, s, t,
+               c->walls, sn, tn, tail, open_half);
 }
 template <int LPP>
 void launch_fused_ea_w(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail)
@@ -399,14 +438,15 @@ void launch_fused_ea_w(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t,
            c->clock.get(), q, c->grid, c->phys, s, t, c->walls, sn, tn, tail);
 }
 // tail = 0: without the clock workgroup (kernel timing)
-void launch_fused_ea(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail = 1)
+void launch_fused_ea(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail = 1,
+                     int open_half = 0)
 {
     switch (c->lpp) {  // 16 / 32 lanes per particle: the compact kernels; fewer: their large-channel forms
         case 2: launch_fused_ea_w<2>(c, q, s, t, sn, tn, tail); break;
         case 4: launch_fused_ea_w<4>(c, q, s, t, sn, tn, tail); break;
         case 8: launch_fused_ea_w<8>(c, q, s, t, sn, tn, tail); break;
-        case 16: launch_fused_ea_t<16>(c, q, s, t, sn, tn, tail); break;
-        case 32: launch_fused_ea_t<32>(c, q, s, t, sn, tn, tail); break;
+        case 16: launch_fused_ea_t<16>(c, q, s, t, sn, tn, tail, open_half); break;
+        case 32: launch_fused_ea_t<32>(c, q, s, t, sn, tn, tail, open_half); break;
         default: throw Error(SPHX_ERR_STATE, "SPHX:Ctx:fuse", "internal: fused E|A launch at this lane count");
     }
 }
@@ -437,8 +477,8 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     // Dual-rate loop: passes CD and E of the inner sub-steps 1 .. n_in-1 (CD of sub-step 0 comes first, E of the last
     // sub-step after).  Sub-step m reads the velocities W_m and writes W_m+1; the W alternate between the step's output
     // array and vel2 so that the last one lands in the output array.
-    auto inner_substeps = [c, q, &s](FluidTmp &t) {
-        if (c->n_in <= 1) { launch_physics_any(c, q, s, t, 0, 3); return; }
+    auto inner_substeps = [c, q, &s](FluidTmp &t, int open_half) {
+        if (c->n_in <= 1) { launch_physics_any(c, q, s, t, 0, 3, 0, 0, 0, open_half); return; }
         double2 *const w_final = t.veln;
         auto w_of = [&](int m) { return ((c->n_in - m) & 1) ? c->vel2.get() : w_final; };  // W_m, m = 1 .. n_in
         FluidSet sm = s;
@@ -456,10 +496,12 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         FluidTmp t = c->tmp_par[q], tn = c->tmp_par[1 - q];
         const FluidSet o = c->view(1 - q, l);
         t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+        // fuse_eab: pass B came with it as well (and the half-step records are still open) -- two launches
+        const int kgc_done = (c->fuse_eab && pos != 0) ? 1 : 0;
         if (pos == 0) launch_physics_any(c, q, s, t, 0, 1, 1);
-        launch_physics_any(c, q, s, t, 0, 2);
-        inner_substeps(t);
-        launch_fused_ea(c, q, s, t, o, tn);
+        if (!kgc_done) launch_physics_any(c, q, s, t, 0, 2);
+        inner_substeps(t, kgc_done);
+        launch_fused_ea(c, q, s, t, o, tn, 1, kgc_done);
         return;
     }
     if (!rebuild) {
@@ -479,10 +521,11 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     }
     if (c->fuse_ea) {  // re-binning step: pass A came with the previous step (or stands alone at pos 0), E has a launch of its own
         FluidTmp t = c->tmp_par[q];
+        const int kgc_done = (c->fuse_eab && pos != 0) ? 1 : 0;
         if (pos == 0) launch_physics_any(c, q, s, t, 1, 1, 1);
-        launch_physics_any(c, q, s, t, 1, 2);
-        inner_substeps(t);
-        launch_physics_any(c, q, s, t, 1, 4);
+        if (!kgc_done) launch_physics_any(c, q, s, t, 1, 2);
+        inner_substeps(t, kgc_done);
+        launch_physics_any(c, q, s, t, 1, 4, 0, 0, 0, kgc_done);
     } else {
         launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
     }
@@ -779,7 +822,7 @@ void forced_rebuild(sphx_ctx *c)
     const bool again = c->n_forced_rebuilds > 0 && now - c->cool_until <= 2 * (int64_t)c->rebuild_every;
     c->cool_len = again ? std::min<int64_t>(2 * std::max<int64_t>(c->cool_len, 16), 1024) : 16;
     c->cool_until = now + c->cool_len;
-    if (getenv("SPHX_DEBUG"))
+    if (debug_switches().log)
         fprintf(stderr, "sphx: forced rebuild #%lld at step %lld (drift bound hit): re-binning every step for %lld steps\n",
                 (long long)c->n_forced_rebuilds + 1, (long long)now, (long long)c->cool_len);
     c->last_forced_step = now;
@@ -867,7 +910,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->vpart.alloc(c->n_vpart);
     // Small channels with a skin: move steps are 4 launches, the clock update rides in pass E (continuity_tail);
     // vpart entries then double as "ready" flags and start out empty (all ones)
-    c->tail_clock = c->skin > 0.0 && !c->is_slab && !c->dyn && c->n_vpart <= 2048 && !std::getenv("SPHX_NO_TAIL_CLOCK");
+    c->tail_clock = c->skin > 0.0 && !c->is_slab && !c->dyn && c->n_vpart <= 2048 && !debug_switches().no_tail_clock;
     // (skinned slabs: the same hand-over feeds slab_seal_tail)
     const bool vpart_flags = c->tail_clock || (c->is_slab && c->rebuild_every > 1);
     SPHX_HIP(hipMemsetAsync(c->vpart.get(), vpart_flags ? 0xFF : 0, (size_t)c->n_vpart * sizeof(double), c->stream));
@@ -882,11 +925,14 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->nl_idx.alloc(stride * nl_cap);
     c->nl_cnt.alloc(stride);
     c->nl_cnt.zero(c->stream);
+    const size_t nl_words = (size_t)(nl_cap + 1) / 2;  // two 16-bit rows per word
+    if (c->walk_kernels) { c->nl_pk.alloc(stride * std::max<size_t>(nl_words, 2)); c->nl_pk.zero(c->stream); }
     const int sl_cap = c->skin > 0.0 ? (3 * nl_cap + 1) / 2 : 0;
     if (sl_cap) {
         c->sl_idx.alloc(stride * sl_cap);
         c->sl_cnt.alloc(stride);
         c->sl_cnt.zero(c->stream);
+        if (c->walk_kernels) { c->sl_pk.alloc(stride * std::max<size_t>((size_t)(sl_cap + 1) / 2, 4)); c->sl_pk.zero(c->stream); }
     }
     const double sl_r = 2.0 * c->prm.h + c->skin;
     c->flags.alloc(1);
@@ -898,9 +944,9 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), nullptr};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, nullptr};
     // E|A fusion: small static-schedule channels on the compact kernels (the clock rides in the tail workgroup)
-    c->fuse_ea = c->tail_clock && (c->lpp >= 16 || (c->walk_kernels && !c->lds_tiles_be && c->lpp >= 2)) && !std::getenv("SPHX_NO_FUSE_EA");
+    c->fuse_ea = c->tail_clock && (c->lpp >= 16 || (c->walk_kernels && !c->lds_tiles_be && c->lpp >= 2)) && !debug_switches().no_fuse_ea;
     c->tmp_par[0] = c->tmp;
     c->tmp_par[1] = c->tmp;
     if (c->fuse_ea) {
@@ -908,12 +954,26 @@ void ctx_alloc(sphx_ctx *c, int cap)
         c->nl_idx2.alloc(stride * nl_cap); c->nl_cnt2.alloc(stride); c->nl_cnt2.zero(c->stream);
         c->tmp_par[1].a = c->fa2.get(); c->tmp_par[1].vol = c->fvol2.get();
         c->tmp_par[1].nl_idx = c->nl_idx2.get(); c->tmp_par[1].nl_cnt = c->nl_cnt2.get();
+        if (c->walk_kernels) {
+            c->nl_pk2.alloc(stride * std::max<size_t>(nl_words, 2)); c->nl_pk2.zero(c->stream);
+            c->tmp_par[1].nl_pk = c->nl_pk2.get();
+        }
     }
     // Opt-in dual-rate loop (sphx_params::dual_rate): small channels on the compact kernels, where the fused launches give
     // the step a fixed shape.  The number of inner sub-steps is fixed per context (the graphs are static): how many acoustic
     // steps fit into the viscous / body-force step, at most dual_rate.  Fine channels are viscous-limited: n_in = 1 there.
     c->n_in = (c->fuse_ea && c->lpp >= 16) ? dual_rate_substeps(c->prm) : 1;
     if (c->n_in > 1) { c->vel2.alloc(cap); c->vel2.zero(c->stream); }
+    // two launches per step: compact kernels, single-rate loop
+    c->fuse_eab = c->fuse_ea && c->lpp >= 16 && c->n_in == 1 && !debug_switches().no_fuse_kgc;
+    if (c->fuse_eab) {
+        c->sl_tot.alloc(cap); c->sl_tot.zero(c->stream);
+        c->fB2.alloc(cap); c->fB2.zero(c->stream);
+        c->tmp.sl_tot = c->sl_tot.get();
+        c->tmp_par[0].sl_tot = c->sl_tot.get();
+        c->tmp_par[1].sl_tot = c->sl_tot.get();
+        c->tmp_par[1].B = c->fB2.get();
+    }
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
@@ -1019,6 +1079,27 @@ void y_extent(const double *py, int n_total, double &y_min, double &y_max)
     require(std::isfinite(y_min) && std::isfinite(y_max), "SPH:Neighbor:pos", "pos must be finite.");
 }
 
+// Which kernel forms the context runs, once lanes per particle and the grid are known.  Up to 8 lanes per particle: the
+// large-channel ("_w") forms, whose lists hold fluid neighbours as 16-bit index differences -- a neighbour sits at most one
+// cell column (+ a few cells) away, so a column must hold well under 2^15 particles; a grid with taller columns (a channel
+// thousands of particles high) goes to 16 lanes per particle and the compact kernels instead.
+void choose_kernel_forms(sphx_ctx *c, bool lpp_given, double column_load, int n_resident)
+{
+    if (c->lpp <= 8 && 1.3 * column_load + 64.0 > (double)kDeltaMax) {
+        if (lpp_given)
+            throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "cell columns too populous for the 16-bit neighbour lists of the "
+                                                      "large-channel kernels: use lanes_per_particle >= 16 (or 0 = auto)");
+        c->lpp = 16;
+    }
+    const DebugSwitches &dbg = debug_switches();
+    c->walk_kernels = c->lpp <= 8;
+    c->sweep_kernels = c->walk_kernels;
+    c->lds_tiles = c->walk_kernels && !dbg.no_lds_tiles;  // (65 k particles: 46.8 with, 46.3 us/step without;
+    // 100-130 k: equal; 194 k: 96.4 / 97.1; 259 k: 117.3 / 119.5; 360 k: 145.8 / 151.0 -- kept on at every size)
+    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= 2000000;
+    c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
+}
+
 void check_lpp(int lpp)
 {
     require(lpp == 1 || lpp == 2 || lpp == 4 || lpp == 8 || lpp == 16 || lpp == 32, "SPHX:Ctx:lpp",
@@ -1040,12 +1121,6 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(nf);
     check_lpp(c->lpp);
-    c->walk_kernels = c->lpp <= 8 && !std::getenv("SPHX_NO_WALK_KERNELS");  // (the environment switches are for A/B runs)
-    c->sweep_kernels = c->walk_kernels && !std::getenv("SPHX_NO_SWEEP_KERNELS");
-    c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");  // (65 k particles: 46.8 with, 46.3 us/step without;
-    // 100-130 k: equal; 194 k: 96.4 / 97.1; 259 k: 117.3 / 119.5; 360 k: 145.8 / 151.0 -- kept on at every size)
-    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && c->nf >= 2000000;
-    c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
     c->spg = prm->steps_per_graph > 0 ? prm->steps_per_graph : 40;  // measured at C2: 10 -> 25.4, 40 -> 25.1, 80 -> 24.8 us/step
     if (c->spg & 1) c->spg += 1;
 
@@ -1068,7 +1143,7 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // dual-rate loop: a slot moves particles n_sub times as far.  Same eligibility as ctx_alloc's n_in (the fused E|A launch
     // with the clock in its tail workgroup: a skin, static schedule, <= 2048 workgroups, compact kernels)
     const bool dual_ok = c->lpp >= 16 && !c->is_slab && K > 1 && prm->dynamic_rebin != 1 &&
-                         div_up((size_t)nf * c->lpp, kBlock) <= 2048 && !std::getenv("SPHX_NO_TAIL_CLOCK") && !std::getenv("SPHX_NO_FUSE_EA");
+                         div_up((size_t)nf * c->lpp, kBlock) <= 2048 && !debug_switches().no_tail_clock && !debug_switches().no_fuse_ea;
     const int n_sub = dual_ok ? dual_rate_substeps(*prm) : 1;
     if (n_sub > 1 && prm->rebuild_every <= 0) K = std::max(2, K / n_sub);
     const double d_step = 0.035 * prm->h * n_sub;
@@ -1103,6 +1178,7 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     g.own_hi = std::numeric_limits<double>::infinity();
     c->grid = g;
     c->phys = make_phys(prm);
+    choose_kernel_forms(c, prm->lanes_per_particle > 0, (double)nf / g.ncx, nf);
 
     SPHX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     SPHX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_clock), sizeof(Clock), hipHostMallocDefault));
@@ -1365,7 +1441,7 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
     if (force_prior) { unsort_o(c->ffp.get(), 2, 0, 0); unsort_o(c->ffp.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force_prior, 2); }
     if (Vol) { unsort_o(c->tmp_par[c->fuse_ea ? c->out_par : 0].a, 4, 0, 0); unsort_w(c->wa.get(), 4, 0, 0); out(Vol, 1); }
     if (B) {
-        for (int k = 0; k < 4; ++k) unsort_o(c->fB.get(), 4, k, k);
+        for (int k = 0; k < 4; ++k) unsort_o(c->tmp_par[c->fuse_ea ? c->out_par : 0].B, 4, k, k);
         fill_w(0, 1.0); fill_w(1, 0.0); fill_w(2, 0.0); fill_w(3, 1.0);
         out(B, 4);
     }
@@ -1509,6 +1585,7 @@ SPHX_EXPORT int sphx_ctx_profile_enable(sphx_ctx *c, int on)
     SPHX_HIP(hipStreamSynchronize(c->stream));
     c->timer.collect();
     c->profiling = on != 0;
+    c->timer.timer_log = debug_switches().log;
     return SPHX_OK;
     SPHX_CATCH
 }
@@ -1568,11 +1645,12 @@ SPHX_EXPORT int sphx_ctx_tuning(sphx_ctx *c, int *lanes_per_particle, int *steps
     SPHX_CATCH
 }
 
-SPHX_EXPORT int sphx_ctx_schedule(sphx_ctx *c, int *fuse_ea, int *tail_clock, int *dynamic, int64_t *rebins)
+SPHX_EXPORT int sphx_ctx_schedule(sphx_ctx *c, int *fuse_ea, int *fuse_kgc, int *tail_clock, int *dynamic, int64_t *rebins)
 {
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     if (fuse_ea) *fuse_ea = c->fuse_ea ? 1 : 0;
+    if (fuse_kgc) *fuse_kgc = c->fuse_eab ? 1 : 0;
     if (tail_clock) *tail_clock = c->tail_clock ? 1 : 0;
     if (dynamic) *dynamic = c->dyn ? 1 : 0;
     if (rebins) *rebins = c->dyn ? (int64_t)c->h_clock->n_rebins : c->n_rebins;
@@ -1693,11 +1771,7 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
 
     c->lpp = prm->lanes_per_particle > 0 ? prm->lanes_per_particle : pick_lpp(n_local);
     check_lpp(c->lpp);
-    c->walk_kernels = c->lpp <= 8 && !std::getenv("SPHX_NO_WALK_KERNELS");  // (the environment switches are for A/B runs)
-    c->sweep_kernels = c->walk_kernels && !std::getenv("SPHX_NO_SWEEP_KERNELS");
-    c->lds_tiles = c->walk_kernels && !std::getenv("SPHX_NO_LDS_TILES");
-    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_local >= 2000000;
-    c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
+    choose_kernel_forms(c, prm->lanes_per_particle > 0, per_col, n_local);
     c->spg = 2;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else SPHX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -1749,34 +1823,10 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
 
 namespace {
 
-// run one half of a slab step: replay its captured graph, (re)capturing when the caller's buffers changed
+// run one half of a slab step (whole steps are replayed as graphs by sphx_slab_graph_prepare; graphs of half a step --
+// the exchange sits between the halves -- cost more host time than the ten plain launches they held)
 template <typename Body>
-void slab_half(sphx_ctx *c, int half, int q, const void *const key[3], Body &&body)
-{
-    // Measured (one rank, 5 760 particles, exchange stubbed out): replaying a 6- and a 4-kernel graph per step costs
-    // 105 us/step of host time (hipGraphLaunch is ~50 us apiece on ROCm 7.2, the device waits); ten plain launches
-    // cost 36 us of host time and the step is device-bound at 70 us.  Graphs only pay when they hold many steps, as
-    // in the single-GPU loop; a slab half-step cannot (the exchange sits between the halves).
-    static const bool use_graph = std::getenv("SPHX_SLAB_GRAPH") != nullptr;
-    if (c->profiling || !use_graph) { body(); return; }
-    hipGraphExec_t &exec = c->slab_graph[half][q];
-    const bool same = exec && c->slab_key[half][0] == key[0] && c->slab_key[half][1] == key[1] && c->slab_key[half][2] == key[2];
-    if (!same) {
-        for (int k = 0; k < 2; ++k)
-            if (c->slab_graph[half][k]) { (void)hipGraphExecDestroy(c->slab_graph[half][k]); c->slab_graph[half][k] = nullptr; }
-        for (int k = 0; k < 3; ++k) c->slab_key[half][k] = key[k];
-    }
-    if (!exec) {
-        hipGraph_t g = nullptr;
-        SPHX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        try { body(); } catch (...) { (void)hipStreamEndCapture(c->stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
-        SPHX_HIP(hipStreamEndCapture(c->stream, &g));
-        const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        SPHX_HIP(e);
-    }
-    SPHX_HIP(hipGraphLaunch(exec, c->stream));
-}
+void slab_half(sphx_ctx *, int, int, const void *const[3], Body &&body) { body(); }
 
 }  // namespace
 
@@ -2720,7 +2770,7 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     else if (n == "k_kgc") only = 2;
     else if (n == "k_forces") only = 3;
     else if (n == "k_continuity" || n == "k_continuity_clock") only = 4;
-    else if (n == "k_continuity_density" && c->fuse_ea) only = 5;  // pass E and the next pass A in one launch
+    else if ((n == "k_continuity_density" || n == "k_continuity_density_kgc") && c->fuse_ea) only = 5;  // pass E and the next pass A (and B) in one launch
     require(only != 0, "SPHX:Ctx:kernel", "time_kernel knows k_density, k_kgc, k_forces, k_continuity (and k_continuity_density)");
     read_clock(c);
     if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
@@ -2735,11 +2785,19 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         const FluidSet fs = c->view(c->cur, c->lay);
         const int dmode = c->dyn ? 3 : (c->skin > 0.0 ? (c->pos == 0 ? 1 : 2) : 0);
         const FluidTmp &tt = c->tmp_par[c->fuse_ea ? c->cur : 0];  // (fuse_ea: the records / list of the current state parity)
+        const int kgc_done = (c->fuse_eab && c->pos != 0) ? 1 : 0;
+        DevBuf<double4> keep_B;
         // make every temporary the timed kernel reads valid.  Where pass A of the coming step came with the last step's final
         // launch its list and records are there already, and stay: a timing call should not change what follows (the
         // stand-alone pass is a different kernel and may round differently in the last bit).
+        // (fuse_eab: the KGC matrices of the coming step are there as well, the half-step records still open -- pass B is
+        // skipped, or, when it is the kernel to be timed, its matrices are set aside and put back)
+        if (kgc_done && only == 2) {
+            keep_B.alloc(c->cap);
+            SPHX_HIP(hipMemcpyAsync(keep_B.get(), tt.B, (size_t)c->cap * sizeof(double4), hipMemcpyDeviceToDevice, c->stream));
+        }
         if (c->fuse_ea && c->pos != 0) {
-            for (int pass = 2; pass <= 4; ++pass) launch_physics_any(c, c->cur, fs, tt, 0, pass, dmode);
+            for (int pass = kgc_done ? 3 : 2; pass <= 4; ++pass) launch_physics_any(c, c->cur, fs, tt, 0, pass, dmode, 0, 0, kgc_done);
         } else {
             launch_physics_any(c, c->cur, fs, tt, 0, 0, dmode);
         }
@@ -2749,9 +2807,9 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
                 FluidTmp te = tt;
                 const FluidSet o = c->view(1 - c->cur, c->lay);
                 te.posn = o.pos; te.veln = o.vel; te.drhon = o.drho;
-                launch_fused_ea(c, c->cur, fs, te, o, c->tmp_par[1 - c->cur], 0);
+                launch_fused_ea(c, c->cur, fs, te, o, c->tmp_par[1 - c->cur], 0, kgc_done);
             } else {
-                launch_physics_any(c, c->cur, fs, tt, 0, only, dmode);
+                launch_physics_any(c, c->cur, fs, tt, 0, only, dmode, 0, 0, only >= 3 ? kgc_done : 0);
             }
         }
         SPHX_HIP(hipStreamEndCapture(c->stream, &g));
@@ -2764,6 +2822,8 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         SPHX_HIP(hipEventRecord(b, c->stream));
         if (c->tail_clock)  // the timed passes stored plain maxima: back to "empty" for the next real step
             SPHX_HIP(hipMemsetAsync(c->vpart.get(), 0xFF, (size_t)c->n_vpart * sizeof(double), c->stream));
+        if (keep_B.get())
+            SPHX_HIP(hipMemcpyAsync(tt.B, keep_B.get(), (size_t)c->cap * sizeof(double4), hipMemcpyDeviceToDevice, c->stream));
         SPHX_HIP(hipStreamSynchronize(c->stream));
         float ms = 0.f;
         SPHX_HIP(hipEventElapsedTime(&ms, a, b));
