@@ -44,9 +44,6 @@ BYTES_PER_WALL["k_continuity_clock"] = BYTES_PER_WALL["k_continuity"]
 # small channels: pass E of a step and pass A of the next one in one launch
 BYTES_PER_FLUID["k_continuity_density"] = BYTES_PER_FLUID["k_continuity"] + BYTES_PER_FLUID["k_density"]
 BYTES_PER_WALL["k_continuity_density"] = BYTES_PER_WALL["k_continuity"] + BYTES_PER_WALL["k_density"]
-# ... and pass B of the next step as well (two launches per step)
-BYTES_PER_FLUID["k_continuity_density_kgc"] = BYTES_PER_FLUID["k_continuity_density"] + BYTES_PER_FLUID["k_kgc"]
-BYTES_PER_WALL["k_continuity_density_kgc"] = BYTES_PER_WALL["k_continuity_density"] + BYTES_PER_WALL["k_kgc"]
 STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
 
 
@@ -100,8 +97,10 @@ def pmc_traffic(name, kernel):
 
 
 def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=0, lattice=False,
-             rebuild_every=0, skin_h=0.0, dynamic=0):
-    """Time `steps` resident steps of one workload; returns (result dict, prm, parts, pos, vel)."""
+             rebuild_every=0, skin_h=0.0, dynamic=0, sustained=None):
+    """Time `steps` resident steps of one workload; returns (result dict, prm, parts, pos, vel).
+    sustained = (skip, n): afterwards run `skip` more steps untimed -- past the point where the synthetic start's jittered
+    lattice has broken up -- and time another n: the rate a long physical run sustains, reported next to the window's."""
     import torch
     prm = cfg.params_from_values(end_time=1e9, **kw)
     parts = geo.init_particles(prm)
@@ -155,13 +154,29 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
                         launch_ms=ms, launch_ms_eager=ms_eager,
                         algorithmic_bytes=alg,
                         step_achieved=(STEP_BYTES_FLUID * nf + STEP_BYTES_WALL * nw) * steps / seconds / 1e9)
+    sus = None
+    if sustained:
+        skip, n_sus = sustained
+        ctx.enqueue_steps(skip)
+        s0 = ctx.sync()
+        ctx.prepare_steps(n_sus)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.enqueue_steps(n_sus)
+        s1 = ctx.sync()
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - t0
+        assert s1["step"] - s0["step"] == n_sus, (s0, s1)
+        sus = dict(value=nt * n_sus / sec, ms_per_step=1e3 * sec / n_sus,
+                   window=f"steps {s0['step']}..{s1['step']} after the start (the jittered lattice has broken up by step ~500)",
+                   forced_rebuilds=ctx.grid_policy()["forced_rebuilds"])
     tuning.update(ctx.grid_policy())
     ctx.close()
     res = dict(value=nt * steps / seconds, ms_per_step=1e3 * seconds / steps, seconds=seconds, roofline=roof,
                kernels_ms={k: round(v["avg_ms"], 6) for k, v in kernels.items()},
                workload=f"{name}: dp={prm.dp}, DL={prm.DL}, DH={prm.DH}, n_fluid={nf}, n_wall={nw}, n_total={nt}, "
                         f"c_f={prm.c_f}, transport_coeff={prm.transport_coeff}; start={start}",
-               cells=[info["n_cell_x"], info["n_cell_y"]], tuning=tuning, replay=replay,
+               cells=[info["n_cell_x"], info["n_cell_y"]], tuning=tuning, replay=replay, sustained=sus,
                sim={"t": st1["t"], "dt": st1["dt_last"], "vmax": st1["vmax"]})
     return res, prm, parts, pos, vel
 
@@ -230,12 +245,14 @@ def main():
         out["aux"] = {}
         # windows end before the synthetic start's jittered lattice breaks up (~500 steps in, a transient during which
         # nearly every step re-bins); sustained figures come from full physical runs
-        for aux_name, aux_steps in (("C4", 300), ("C5", 100)):
+        # ... and, in the same context, the rate sustained once it has (`sustained`: 2 000 / 1 000 steps in)
+        for aux_name, aux_steps, aux_sus in (("C4", 300, (2000, 1000)), ("C5", 100, (1000, 300))):
             try:
-                a = run_case(capi, cfg, geo, aux_name, dict(WORKLOADS[aux_name]), aux_steps, 40, 16)[0]
-                out["aux"][aux_name] = {k: a[k] for k in ("value", "ms_per_step", "roofline", "kernels_ms", "workload", "tuning")}
-                out["aux"][aux_name]["window"] = (f"{aux_steps} steps right after a developed start; sustained figures of full "
-                                                  "physical runs (about 10 % lower: disordered particles idle more lanes): DESIGN.md section 4 / profiles/r02_longrun_*.json")
+                a = run_case(capi, cfg, geo, aux_name, dict(WORKLOADS[aux_name]), aux_steps, 40, 16, sustained=aux_sus)[0]
+                out["aux"][aux_name] = {k: a[k] for k in ("value", "ms_per_step", "roofline", "kernels_ms", "workload", "tuning", "sustained")}
+                out["aux"][aux_name]["window"] = (f"{aux_steps} steps right after a developed start; `sustained` = the same context "
+                                                  "further in (disordered particles idle more lanes and the drift bound triggers "
+                                                  "re-binnings); full physical runs: DESIGN.md section 4 / profiles/r0*_longrun_*.json")
             except Exception as e:  # never let the side measurements break the headline line
                 out["aux"][aux_name] = {"error": repr(e)}
         # second half of the north-star metric: u(y) L2 vs the analytic parabola after the reference's full run

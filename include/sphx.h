@@ -236,11 +236,10 @@ int sphx_ctx_grid_policy(sphx_ctx *ctx, int *rebuild_every, double *skin, int64_
 int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph);
 
 /* The launch schedule the context runs: fuse_ea = pass E of a step and pass A of the next one share a launch
- * (three launches per step), fuse_kgc = pass B of the next step rides in that launch as well (two launches per step),
- * tail_clock = the clock update rides in the last launch of a step, dynamic = the device decides when to re-bin;
- * rebins = re-binnings carried out by step slots so far (scheduled ones; dynamic contexts: all of them), not counting
- * the forced ones sphx_ctx_grid_policy reports. */
-int sphx_ctx_schedule(sphx_ctx *ctx, int *fuse_ea, int *fuse_kgc, int *tail_clock, int *dynamic, int64_t *rebins);
+ * (three launches per step), tail_clock = the clock update rides in the last launch of a step, dynamic = the device
+ * decides when to re-bin; rebins = re-binnings carried out by step slots so far (scheduled ones; dynamic contexts:
+ * all of them), not counting the forced ones sphx_ctx_grid_policy reports. */
+int sphx_ctx_schedule(sphx_ctx *ctx, int *fuse_ea, int *tail_clock, int *dynamic, int64_t *rebins);
 
 /* Inner sub-steps per step slot: 1 unless sphx_params::dual_rate asked for the dual-rate loop and the context is
  * eligible.  With n_inner > 1 a "step" of sphx_status / max_steps is an outer step (t advances by n_inner * dt_last). */

@@ -200,9 +200,9 @@ class Context:
 
     def schedule(self):
         """Launch schedule in force and the re-binnings carried out by step slots so far (sphx_ctx_schedule)."""
-        a, k, b, d, r = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
-        check(lib().sphx_ctx_schedule(self._h, C.byref(a), C.byref(k), C.byref(b), C.byref(d), C.byref(r)))
-        return dict(fuse_ea=a.value, fuse_kgc=k.value, tail_clock=b.value, dynamic=d.value, rebins=r.value)
+        a, b, d, r = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
+        check(lib().sphx_ctx_schedule(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(r)))
+        return dict(fuse_ea=a.value, tail_clock=b.value, dynamic=d.value, rebins=r.value)
 
     def substeps(self) -> int:
         """Inner sub-steps per step slot (1 = the reference's single-rate loop, see sphx_params.dual_rate)."""

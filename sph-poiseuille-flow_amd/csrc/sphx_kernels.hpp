@@ -145,8 +145,6 @@ struct FluidTmp {
     // list bytes the passes move (at 6 M particles the lists were 40-60 % of every pass's HBM traffic).  nullptr: compact kernels.
     int *nl_pk, *sl_pk;
     int has_slack;     // 1: the arrays hold markedly more slots than particles (slabs), see beyond_population
-    int *sl_tot;       // [cap] entries of each particle's superset list (compact kernels with the KGC pass folded into the
-                       // fused E|A launch: volume_two_hop walks a NEIGHBOUR's superset list); nullptr: not kept
     double *seal_out;  // skinned slabs: the tail workgroup of pass E leaves {max |v|, max drift} of the owned particles here
                        // (the input of the step's max all-reduce), see slab_seal_tail
 };
@@ -351,41 +349,11 @@ __device__ __forceinline__ int wrap_index(int k, int n) { return k < 0 ? k + n :
 // bid / nblk: the workgroup's index among the nblk workgroups of this pass (the fused launch k_continuity_density runs the
 // pass in a sub-range of its grid).  half: also write the half-step density / pressure (needs the step's dt; the fused
 // launch runs pass A of the NEXT step, whose dt is not known yet -- pass B completes the record there).
-// Volume of particle k at the positions of state `s`, summed from k's OWN superset list by one lane ("two hops": the KGC
-// matrix of a particle needs its neighbours' volumes, which pass A of the same launch is still computing -- each lane
-// recomputes the one it needs; ~36 candidates).  Same kernel sum as pass A, in list order instead of the shuffle tree's.
-template <int LPP>
-__device__ __forceinline__ double volume_two_hop(const Grid &g, const Phys &ph, const FluidSet &s, const FluidTmp &t,
-                                                 const Walls &w, int k)
-{
-    const double2 pk = s.pos[k];
-    const double mk = s.mass[k];
-    const int tot = t.sl_tot[k];
-    const size_t col0 = (size_t)k * LPP;
-    double s_in = 0.0, s_ct = 0.0;
-    for (int m = 0; m < tot; ++m) {
-        const int e = t.sl_idx[(size_t)(m / LPP) * t.nl_stride + col0 + (m % LPP)];
-        const bool wall = (e & kWallBit) != 0;
-        const int j = e & (kWallBit - 1);
-        const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[j];
-        const double dx = min_image(g, pk.x - pj.x), dy = pk.y - pj.y;
-        const double r2 = dx * dx + dy * dy;
-        if (r2 > kR2Min && r2 < ph.kc.rcut2) {
-            const double W = spline_W(ph.kc, r2 * rsqrt(r2));
-            if (wall) s_ct += W * w.a[j].x;
-            else s_in += W;
-        }
-    }
-    return mk / density_from_sigma(ph.w0 + s_in, s_ct, mk, ph.rho0, ph.inv_sigma0);
-}
-
-// KGC (MODE 2 only): also the kernel-gradient-correction matrix of the particle (pass B, see k_kgc) from the same
-// candidates, the neighbours' volumes by volume_two_hop -> t.B
-template <int LPP, int MODE, bool KGC = false>
+template <int LPP, int MODE>
 __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                              const FluidTmp &t, const Walls &w, int bid, int nblk, bool half)
 {
-    static_assert(!KGC || MODE == 2, "the KGC pass rides on the list-walking pass A only");
+
     SPHX_PASS_INDEX_AT(bid, nblk);
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const int ci = in_cap ? s.cell[i] : 0;
@@ -450,7 +418,6 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
     };
     constexpr bool walk = MODE == 2;
     constexpr bool record = MODE == 1;  // also write the superset list
-    double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0;  // (KGC)
     if (walk) {
         const int rows = LPP == 1 ? ns : __shfl(ns, gbase);  // lane 0 of the group owns the most rows
         if (active) {
@@ -468,19 +435,9 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                         acc = true;
-                        const double inv_r = rsqrt(r2), r = r2 * inv_r;
-                        const double W = spline_W(ph.kc, r);
+                        const double W = spline_W(ph.kc, r2 * rsqrt(r2));
                         if (wall) s_ct += W * Volw;
                         else s_in += W;
-                        if (KGC) {  // the term of k_kgc for this neighbour
-                            const double Volj = wall ? Volw : volume_two_hop<LPP>(g, ph, s, t, w, k);
-                            const double ex = dx * inv_r, ey = dy * inv_r;
-                            const double fxj = spline_dW(ph.kc, r) * Volj;
-                            a11 -= dx * (fxj * ex);
-                            a12 -= dx * (fxj * ey);
-                            a21 -= dy * (fxj * ex);
-                            a22 -= dy * (fxj * ey);
-                        }
                     }
                 }
                 // wall candidates sit behind the fluid ones: the fluid count is the count reached before the first row
@@ -581,19 +538,8 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
         t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
     if (record && tid < t.nl_stride)
         t.sl_cnt[tid] = (scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0) | ((scnt_fl > sub ? (scnt_fl - sub + LPP - 1) / LPP : 0) << 16);
-    if (record && t.sl_tot && active && sub == 0) t.sl_tot[i] = scnt;
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
-    if (KGC) {
-        a11 = group_sum<LPP>(a11);
-        a12 = group_sum<LPP>(a12);
-        a21 = group_sum<LPP>(a21);
-        a22 = group_sum<LPP>(a22);
-        if (active && sub == 0) {
-            const Mat2 B = kgc_from_A(a11, a12, a21, a22);
-            t.B[i] = make_double4(B.m11, B.m12, B.m21, B.m22);
-        }
-    }
     if (active && sub == 0) {
         const double m = mass_i;
         const double rho = density_from_sigma(ph.w0 + s_in, s_ct, m, ph.rho0, ph.inv_sigma0);
@@ -693,17 +639,13 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
 // later = 1 (dual-rate loop, inner sub-steps after the first): the pressure part only -- viscous force and gravity
 // are those of the first sub-step (t.fp), there is no transport shift, the particle moves on from t.posn; pair geometry
 // stays that of the start of the outer step (s.pos), velocities are the latest ones (s.vel = the previous sub-step's).
-// open_half = 1: the {p_half, rho_half} part of the records is still open (pass A ran inside the previous step's last
-// launch, before this step's dt existed, and the KGC pass that used to close it rode in that launch too): close it on the
-// fly, for the particle and for every neighbour (one more 8-byte gather: drho), and leave rho_half in t.rho_out for pass E.
 template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
-                                                   FluidTmp t, Walls w, int later, int open_half)
+                                                   FluidTmp t, Walls w, int later)
 {
     SPHX_PASS_INDEX();
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const double2 vi = in_cap ? s.vel[i] : make_double2(0.0, 0.0);
-    const double drho_own = (open_half && in_cap) ? s.drho[i] : 0.0;
     const double4 ai = in_cap ? t.a[i] : make_double4(1.0, 0.0, 0.0, 0.0);
     const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
     const double mi = in_cap ? s.mass[i] : 1.0;
@@ -724,9 +666,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     const double h = ph.kc.h;
     double ax = 0.0, ay = 0.0, ix = 0.0, iy = 0.0, px = 0.0, py = 0.0, d2 = 0.0;
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
-    const double Voli = ai.x;
-    double p_i = ai.y, rhoh_i = ai.z;
-    if (open_half) half_state(ph, ai.w, drho_own, dt, rhoh_i, p_i);
+    const double Voli = ai.x, p_i = ai.y, rhoh_i = ai.z;
     const double b11i = Bi.x, b12i = Bi.y, b21i = Bi.z, b22i = Bi.w;
     int first_wall = 1 << 20;  // wall neighbours are appended behind the fluid ones: this lane's rows >= first_wall
     if (active) {
@@ -736,14 +676,11 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
             if (!(e & kWallBit)) {
                 const double2 pj = s.pos[k], vj = s.vel[k];
                 const double4 aj = t.a[k], Bj = t.B[k];
-                const double drho_j = open_half ? s.drho[k] : 0.0;
                 const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
                 const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
                 const double ex = dx * inv_r, ey = dy * inv_r;
                 const double dW = spline_dW(ph.kc, r);
                 const double Volj = aj.x;
-                double p_j = aj.y, rhoh_j = aj.z;
-                if (open_half) half_state(ph, aj.w, drho_j, dt, rhoh_j, p_j);
                 const double tx = (b11i + Bj.x) * ex + (b12i + Bj.y) * ey;
                 const double ty = (b21i + Bj.z) * ex + (b22i + Bj.w) * ey;
                 const double eBe = ex * tx + ey * ty;
@@ -759,7 +696,8 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
                     iy -= dWVj * ty;
                 }
                 // pressure (Riemann-dissipated face pressure)
-                const double rho_bar = 0.5 * (rhoh_i + rhoh_j);
+                const double p_j = aj.y;
+                const double rho_bar = 0.5 * (rhoh_i + aj.z);
                 const double un_l = vxi * ex + vyi * ey, un_r = vxj * ex + vyj * ey;
                 const double beta = riemann_beta(un_l, un_r, ph.c_f);
                 const double p_avg = 0.5 * (p_i + p_j);
@@ -831,7 +769,6 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         t.veln[i] = make_double2(vxn, vyn);
         if (!later) t.fp[i] = make_double2(fpx, fpy);
         t.f[i] = make_double2(fx, fy);
-        if (open_half) t.rho_out[i] = rhoh_i;  // (pass E takes it from here and then stores the final density)
     }
     // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
 #pragma unroll
@@ -1764,7 +1701,7 @@ __device__ __forceinline__ void slab_seal_tail(const Clock *clk, int q, const Fl
 template <int LPP, bool WALK, int TILE>
 __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                                 const FluidTmp &t, const Walls &w, int do_hist, int tail, int bid, int nb,
-                                                double2 *c_pos, double2 *c_vel, double *c_vol, int next_half = 0, int open_half = 0)
+                                                double2 *c_pos, double2 *c_vel, double *c_vol, int next_half = 0)
 {
     const int blk = xcd_block(bid, nb);
     const int tid = blk * kBlock + threadIdx.x;
@@ -1791,8 +1728,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const int e_row3 = (!WALK && LPP <= 8) ? t.nl_idx[3 * (size_t)t.nl_stride + tid] : 0;
     const bool lead = in_cap && sub == 0;
     const double4 a_own = lead ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
-    // (open_half: the record's half-step part was never closed -- pass CD computed rho_half and left it in rho_out)
-    const double rhoh_i = (open_half && lead) ? t.rho_out[i] : a_own.z;
+    const double rhoh_i = a_own.z;
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
     const double dt = clk->dt;
     if (!clk->run[q]) return;
@@ -1911,8 +1847,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
 
 template <int LPP, bool WALK, int TILE>
 __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
-                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half,
-                                                       int open_half)
+                                                       FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
@@ -1923,7 +1858,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
         else continuity_tail(clk, q, ph, t, nb);
         return;
     }
-    continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol, next_half, open_half);
+    continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol, next_half);
 }
 
 // Small channels, steps that do not re-bin: pass E of this step and pass A of the NEXT step in one launch, side by
@@ -1933,13 +1868,9 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
 // on the new state s_next, walking the superset list, into the other list / record buffers (t_next) -- without the
 // half-step density and pressure, which need the next step's dt (the tail workgroup of this very launch computes it):
 // pass B of the next step closes that (k_kgc, finish_half); workgroup 2 nb: the clock (continuity_tail).
-// KGC: pass B of the next step rides along as well (density_body<.., KGC>, volume_two_hop) -- a step is then TWO launches,
-// pass CD and this one; pass CD closes the half-step records itself (k_forces, open_half), which is what open_half says
-// about the step pass E belongs to here.
-template <int LPP, bool KGC>
+template <int LPP>
 __global__ __launch_bounds__(kBlock) void k_continuity_density(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
-                                                               Walls w, FluidSet s_next, FluidTmp t_next, int with_tail,
-                                                               int open_half)
+                                                               Walls w, FluidSet s_next, FluidTmp t_next, int with_tail)
 {
     const int nb = ((int)gridDim.x - with_tail) / 2;  // (with_tail = 0: kernel timing, the clock must not advance)
     const int b = (int)blockIdx.x;
@@ -1947,8 +1878,8 @@ __global__ __launch_bounds__(kBlock) void k_continuity_density(Clock *clk, int q
         continuity_tail(clk, q, ph, t, nb);
         return;
     }
-    if (b < nb) continuity_body<LPP, false, 0>(clk, q, g, ph, s, t, w, 0, with_tail, b, nb, nullptr, nullptr, nullptr, 0, open_half);
-    else density_body<LPP, 2, KGC>(clk, q, g, ph, s_next, t_next, w, b - nb, nb, false);
+    if (b < nb) continuity_body<LPP, false, 0>(clk, q, g, ph, s, t, w, 0, with_tail, b, nb, nullptr, nullptr, nullptr);
+    else density_body<LPP, 2>(clk, q, g, ph, s_next, t_next, w, b - nb, nb, false);
 }
 
 // the same with the large-channel forms of the two passes (mid-size channels: 4-8 lanes per particle, clock in the tail)

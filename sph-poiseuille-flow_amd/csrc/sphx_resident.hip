@@ -167,12 +167,6 @@ struct sphx_ctx {
     // (k_continuity_density).  The neighbour list and the {Vol, p, rho_h, rho} records then exist once per state parity:
     // tmp_par[p] is `tmp` with the buffers of parity p; out_par = the parity of the last executed step (its Vol).
     bool fuse_ea = false;
-    // ... and pass B of the next step rides in that launch too (density_body<.., KGC>, volume_two_hop): a step that does not
-    // re-bin is TWO launches, pass CD (which closes the half-step records itself: open_half) and E | A | B + clock.  The
-    // KGC matrices then exist once per state parity like the records (fB2).
-    bool fuse_eab = false;
-    DevBuf<int> sl_tot;
-    DevBuf<double4> fB2;
     bool lds_tiles_a = false;    // pass A's walk gathers the candidate positions from an LDS tile
     bool sweep_kernels = false;  // pass A's cell sweep in its large-channel form (k_density_sweep_w)
     int n_in = 1;                // dual-rate loop: inner sub-steps per step slot (1 = the reference's single-rate loop)
@@ -225,12 +219,11 @@ struct sphx_ctx {
 namespace {
 
 // A/B switches for measurements, all behind ONE environment variable read once per process:
-//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_fuse_kgc,no_lds_tiles,log
+//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_lds_tiles,log
 // (no_tail_clock: the clock update as a launch of its own on every step; no_fuse_ea: passes E and A in separate launches;
-//  no_fuse_kgc: pass B as a launch of its own (three launches per step on small channels);
 //  no_lds_tiles: large-channel passes gather from global memory; log: forced re-binnings and timer problems on stderr)
 struct DebugSwitches {
-    bool no_tail_clock = false, no_fuse_ea = false, no_fuse_kgc = false, no_lds_tiles = false, log = false;
+    bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, log = false;
 };
 const DebugSwitches &debug_switches()
 {
@@ -241,7 +234,6 @@ const DebugSwitches &debug_switches()
         auto has = [&](const char *name) { return ("," + v + ",").find(std::string(",") + name + ",") != std::string::npos; };
         d.no_tail_clock = has("no_tail_clock");
         d.no_fuse_ea = has("no_fuse_ea");
-        d.no_fuse_kgc = has("no_fuse_kgc");
         d.no_lds_tiles = has("no_lds_tiles");
         d.log = has("log");
         return d;
@@ -318,7 +310,7 @@ int dual_rate_substeps(const sphx_params &prm)
 // inner (dual-rate loop, compact kernels only): this launch of pass CD / E belongs to an inner sub-step -- CD does the
 //        pressure part only, E hands the next sub-step its half-step density
 template <int LPP>
-void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode, int tail, int inner, int open_half)
+void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only, int dmode, int tail, int inner)
 {
     const dim3 gp(c->n_blocks_particles), bp(kBlock);
     const Clock *clk = c->clock.get();
@@ -338,9 +330,9 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             }
         }
         if (!only || only == 2) launch(c, "k_kgc", k_kgc<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
-        if (!only || only == 3) launch(c, inner ? "k_forces_inner" : "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, inner, open_half);
+        if (!only || only == 3) launch(c, inner ? "k_forces_inner" : "k_forces", k_forces<LPP>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, inner);
         if (!only || only == 4)
-            launch(c, inner ? "k_continuity_inner" : name_e, k_continuity<LPP, false, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, inner, open_half);
+            launch(c, inner ? "k_continuity_inner" : name_e, k_continuity<LPP, false, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, inner);
     } else {
         // large channels (few lanes per particle): the "_w" forms, see sphx_kernels.hpp -- fluid list entries are 16-bit index
         // differences, so builders and walkers always go together
@@ -372,23 +364,22 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             else launch(c, "k_forces", k_forces_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
         }
         if (!only || only == 4) {
-            if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0, 0);
-            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0, 0);
+            if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
+            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
         }
     }
 }
 
-// open_half: passes CD / E of a step whose half-step records were never closed (see sphx_ctx::fuse_eab)
 void launch_physics_any(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, int do_hist, int only = 0, int dmode = 0,
-                        int tail = 0, int inner = 0, int open_half = 0)
+                        int tail = 0, int inner = 0)
 {
     switch (c->lpp) {
-        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
-        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
-        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
-        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
-        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
-        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode, tail, inner, open_half); break;
+        case 1: launch_physics<1>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 2: launch_physics<2>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 4: launch_physics<4>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 8: launch_physics<8>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 16: launch_physics<16>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
+        case 32: launch_physics<32>(c, q, s, t, do_hist, only, dmode, tail, inner); break;
         default: throw Error(SPHX_ERR_ARG, "SPHX:Ctx:lpp", "lanes_per_particle must be 1,2,4,8,16 or 32");
     }
 }
@@ -420,16 +411,10 @@ void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderA
 }
 
 template <int LPP>
-void launch_fused_ea_t(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail,
-                       int open_half)
+void launch_fused_ea_t(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail)
 {
-    const dim3 grid(2 * c->n_blocks_particles + tail), block(kBlock);
-    if (c->fuse_eab)
-        launch(c, "k_continuity_density_kgc", k_continuity_density<LPP, true>, grid, block, c->clock.get(), q, c->grid, c->phys, s, t,
-               c->walls, sn, tn, tail, open_half);
-    else
-        launch(c, "k_continuity_density", k_continuity_density<LPP, false>, grid, block, c->clock.get(), q, c->grid, c->phys, s, t,
-               c->walls, sn, tn, tail, open_half);
+    launch(c, "k_continuity_density", k_continuity_density<LPP>, dim3(2 * c->n_blocks_particles + tail), dim3(kBlock),
+           c->clock.get(), q, c->grid, c->phys, s, t, c->walls, sn, tn, tail);
 }
 template <int LPP>
 void launch_fused_ea_w(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail)
@@ -438,15 +423,14 @@ void launch_fused_ea_w(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t,
            c->clock.get(), q, c->grid, c->phys, s, t, c->walls, sn, tn, tail);
 }
 // tail = 0: without the clock workgroup (kernel timing)
-void launch_fused_ea(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail = 1,
-                     int open_half = 0)
+void launch_fused_ea(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, const FluidSet &sn, const FluidTmp &tn, int tail = 1)
 {
     switch (c->lpp) {  // 16 / 32 lanes per particle: the compact kernels; fewer: their large-channel forms
         case 2: launch_fused_ea_w<2>(c, q, s, t, sn, tn, tail); break;
         case 4: launch_fused_ea_w<4>(c, q, s, t, sn, tn, tail); break;
         case 8: launch_fused_ea_w<8>(c, q, s, t, sn, tn, tail); break;
-        case 16: launch_fused_ea_t<16>(c, q, s, t, sn, tn, tail, open_half); break;
-        case 32: launch_fused_ea_t<32>(c, q, s, t, sn, tn, tail, open_half); break;
+        case 16: launch_fused_ea_t<16>(c, q, s, t, sn, tn, tail); break;
+        case 32: launch_fused_ea_t<32>(c, q, s, t, sn, tn, tail); break;
         default: throw Error(SPHX_ERR_STATE, "SPHX:Ctx:fuse", "internal: fused E|A launch at this lane count");
     }
 }
@@ -477,8 +461,8 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     // Dual-rate loop: passes CD and E of the inner sub-steps 1 .. n_in-1 (CD of sub-step 0 comes first, E of the last
     // sub-step after).  Sub-step m reads the velocities W_m and writes W_m+1; the W alternate between the step's output
     // array and vel2 so that the last one lands in the output array.
-    auto inner_substeps = [c, q, &s](FluidTmp &t, int open_half) {
-        if (c->n_in <= 1) { launch_physics_any(c, q, s, t, 0, 3, 0, 0, 0, open_half); return; }
+    auto inner_substeps = [c, q, &s](FluidTmp &t) {
+        if (c->n_in <= 1) { launch_physics_any(c, q, s, t, 0, 3); return; }
         double2 *const w_final = t.veln;
         auto w_of = [&](int m) { return ((c->n_in - m) & 1) ? c->vel2.get() : w_final; };  // W_m, m = 1 .. n_in
         FluidSet sm = s;
@@ -496,12 +480,10 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
         FluidTmp t = c->tmp_par[q], tn = c->tmp_par[1 - q];
         const FluidSet o = c->view(1 - q, l);
         t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
-        // fuse_eab: pass B came with it as well (and the half-step records are still open) -- two launches
-        const int kgc_done = (c->fuse_eab && pos != 0) ? 1 : 0;
         if (pos == 0) launch_physics_any(c, q, s, t, 0, 1, 1);
-        if (!kgc_done) launch_physics_any(c, q, s, t, 0, 2);
-        inner_substeps(t, kgc_done);
-        launch_fused_ea(c, q, s, t, o, tn, 1, kgc_done);
+        launch_physics_any(c, q, s, t, 0, 2);
+        inner_substeps(t);
+        launch_fused_ea(c, q, s, t, o, tn);
         return;
     }
     if (!rebuild) {
@@ -521,11 +503,10 @@ void launch_step(sphx_ctx *c, int q, int l, int pos, bool rebuild)
     }
     if (c->fuse_ea) {  // re-binning step: pass A came with the previous step (or stands alone at pos 0), E has a launch of its own
         FluidTmp t = c->tmp_par[q];
-        const int kgc_done = (c->fuse_eab && pos != 0) ? 1 : 0;
         if (pos == 0) launch_physics_any(c, q, s, t, 1, 1, 1);
-        if (!kgc_done) launch_physics_any(c, q, s, t, 1, 2);
-        inner_substeps(t, kgc_done);
-        launch_physics_any(c, q, s, t, 1, 4, 0, 0, 0, kgc_done);
+        launch_physics_any(c, q, s, t, 1, 2);
+        inner_substeps(t);
+        launch_physics_any(c, q, s, t, 1, 4);
     } else {
         launch_physics_any(c, q, s, c->tmp, 1, 0, dmode);
     }
@@ -944,7 +925,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, nullptr};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr};
     // E|A fusion: small static-schedule channels on the compact kernels (the clock rides in the tail workgroup)
     c->fuse_ea = c->tail_clock && (c->lpp >= 16 || (c->walk_kernels && !c->lds_tiles_be && c->lpp >= 2)) && !debug_switches().no_fuse_ea;
     c->tmp_par[0] = c->tmp;
@@ -964,16 +945,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
     // steps fit into the viscous / body-force step, at most dual_rate.  Fine channels are viscous-limited: n_in = 1 there.
     c->n_in = (c->fuse_ea && c->lpp >= 16) ? dual_rate_substeps(c->prm) : 1;
     if (c->n_in > 1) { c->vel2.alloc(cap); c->vel2.zero(c->stream); }
-    // two launches per step: compact kernels, single-rate loop
-    c->fuse_eab = c->fuse_ea && c->lpp >= 16 && c->n_in == 1 && !debug_switches().no_fuse_kgc;
-    if (c->fuse_eab) {
-        c->sl_tot.alloc(cap); c->sl_tot.zero(c->stream);
-        c->fB2.alloc(cap); c->fB2.zero(c->stream);
-        c->tmp.sl_tot = c->sl_tot.get();
-        c->tmp_par[0].sl_tot = c->sl_tot.get();
-        c->tmp_par[1].sl_tot = c->sl_tot.get();
-        c->tmp_par[1].B = c->fB2.get();
-    }
+
     c->tau_part.alloc((size_t)2 * c->n_blocks_flat);
     c->tau_out.alloc(2);
 }
@@ -1441,7 +1413,7 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
     if (force_prior) { unsort_o(c->ffp.get(), 2, 0, 0); unsort_o(c->ffp.get(), 2, 1, 1); fill_w(0, 0.0); fill_w(1, 0.0); out(force_prior, 2); }
     if (Vol) { unsort_o(c->tmp_par[c->fuse_ea ? c->out_par : 0].a, 4, 0, 0); unsort_w(c->wa.get(), 4, 0, 0); out(Vol, 1); }
     if (B) {
-        for (int k = 0; k < 4; ++k) unsort_o(c->tmp_par[c->fuse_ea ? c->out_par : 0].B, 4, k, k);
+        for (int k = 0; k < 4; ++k) unsort_o(c->fB.get(), 4, k, k);
         fill_w(0, 1.0); fill_w(1, 0.0); fill_w(2, 0.0); fill_w(3, 1.0);
         out(B, 4);
     }
@@ -1645,12 +1617,11 @@ SPHX_EXPORT int sphx_ctx_tuning(sphx_ctx *c, int *lanes_per_particle, int *steps
     SPHX_CATCH
 }
 
-SPHX_EXPORT int sphx_ctx_schedule(sphx_ctx *c, int *fuse_ea, int *fuse_kgc, int *tail_clock, int *dynamic, int64_t *rebins)
+SPHX_EXPORT int sphx_ctx_schedule(sphx_ctx *c, int *fuse_ea, int *tail_clock, int *dynamic, int64_t *rebins)
 {
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     if (fuse_ea) *fuse_ea = c->fuse_ea ? 1 : 0;
-    if (fuse_kgc) *fuse_kgc = c->fuse_eab ? 1 : 0;
     if (tail_clock) *tail_clock = c->tail_clock ? 1 : 0;
     if (dynamic) *dynamic = c->dyn ? 1 : 0;
     if (rebins) *rebins = c->dyn ? (int64_t)c->h_clock->n_rebins : c->n_rebins;
@@ -2770,7 +2741,7 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
     else if (n == "k_kgc") only = 2;
     else if (n == "k_forces") only = 3;
     else if (n == "k_continuity" || n == "k_continuity_clock") only = 4;
-    else if ((n == "k_continuity_density" || n == "k_continuity_density_kgc") && c->fuse_ea) only = 5;  // pass E and the next pass A (and B) in one launch
+    else if (n == "k_continuity_density" && c->fuse_ea) only = 5;  // pass E and the next pass A in one launch
     require(only != 0, "SPHX:Ctx:kernel", "time_kernel knows k_density, k_kgc, k_forces, k_continuity (and k_continuity_density)");
     read_clock(c);
     if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);
@@ -2785,19 +2756,11 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         const FluidSet fs = c->view(c->cur, c->lay);
         const int dmode = c->dyn ? 3 : (c->skin > 0.0 ? (c->pos == 0 ? 1 : 2) : 0);
         const FluidTmp &tt = c->tmp_par[c->fuse_ea ? c->cur : 0];  // (fuse_ea: the records / list of the current state parity)
-        const int kgc_done = (c->fuse_eab && c->pos != 0) ? 1 : 0;
-        DevBuf<double4> keep_B;
         // make every temporary the timed kernel reads valid.  Where pass A of the coming step came with the last step's final
         // launch its list and records are there already, and stay: a timing call should not change what follows (the
         // stand-alone pass is a different kernel and may round differently in the last bit).
-        // (fuse_eab: the KGC matrices of the coming step are there as well, the half-step records still open -- pass B is
-        // skipped, or, when it is the kernel to be timed, its matrices are set aside and put back)
-        if (kgc_done && only == 2) {
-            keep_B.alloc(c->cap);
-            SPHX_HIP(hipMemcpyAsync(keep_B.get(), tt.B, (size_t)c->cap * sizeof(double4), hipMemcpyDeviceToDevice, c->stream));
-        }
         if (c->fuse_ea && c->pos != 0) {
-            for (int pass = kgc_done ? 3 : 2; pass <= 4; ++pass) launch_physics_any(c, c->cur, fs, tt, 0, pass, dmode, 0, 0, kgc_done);
+            for (int pass = 2; pass <= 4; ++pass) launch_physics_any(c, c->cur, fs, tt, 0, pass, dmode);
         } else {
             launch_physics_any(c, c->cur, fs, tt, 0, 0, dmode);
         }
@@ -2807,9 +2770,9 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
                 FluidTmp te = tt;
                 const FluidSet o = c->view(1 - c->cur, c->lay);
                 te.posn = o.pos; te.veln = o.vel; te.drhon = o.drho;
-                launch_fused_ea(c, c->cur, fs, te, o, c->tmp_par[1 - c->cur], 0, kgc_done);
+                launch_fused_ea(c, c->cur, fs, te, o, c->tmp_par[1 - c->cur], 0);
             } else {
-                launch_physics_any(c, c->cur, fs, tt, 0, only, dmode, 0, 0, only >= 3 ? kgc_done : 0);
+                launch_physics_any(c, c->cur, fs, tt, 0, only, dmode);
             }
         }
         SPHX_HIP(hipStreamEndCapture(c->stream, &g));
@@ -2822,8 +2785,6 @@ SPHX_EXPORT int sphx_ctx_time_kernel(sphx_ctx *c, const char *name, int reps, do
         SPHX_HIP(hipEventRecord(b, c->stream));
         if (c->tail_clock)  // the timed passes stored plain maxima: back to "empty" for the next real step
             SPHX_HIP(hipMemsetAsync(c->vpart.get(), 0xFF, (size_t)c->n_vpart * sizeof(double), c->stream));
-        if (keep_B.get())
-            SPHX_HIP(hipMemcpyAsync(tt.B, keep_B.get(), (size_t)c->cap * sizeof(double4), hipMemcpyDeviceToDevice, c->stream));
         SPHX_HIP(hipStreamSynchronize(c->stream));
         float ms = 0.f;
         SPHX_HIP(hipEventElapsedTime(&ms, a, b));

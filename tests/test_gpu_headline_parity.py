@@ -2,9 +2,8 @@
 re-binnings.
 
 bench.py's C2 line runs the DEFAULT context: no lanes_per_particle, no rebuild_every -- 32 lanes per particle on the
-compact kernels, cells re-binned every 16th step (K = 16), pass E of step n and passes A and B of step n+1 in one launch
-(k_continuity_density<32, KGC>, `fuse_ea` + `fuse_kgc`: two launches per step, the neighbours' volumes of the KGC sum
-recomputed by volume_two_hop, the half-step records closed inside pass CD).  The other resident tests reach <= 10 steps on that context, i.e. they stop short
+compact kernels, cells re-binned every 16th step (K = 16), pass E of step n and pass A of step n+1 in one launch
+(k_continuity_density, `fuse_ea`).  The other resident tests reach <= 10 steps on that context, i.e. they stop short
 of its first scheduled re-binning (step 16: k_continuity with the cell histogram -> k_clock_scan -> k_scatter ->
 k_reorder -> the stand-alone cell-sweeping k_density<32, build>).  Here C2 (dp 0.025, DL 3: 5 760 particles, the
 metric's own configuration) and C1 (dp 0.04, DL 3: config.ini's size class) run 20 and 35 steps -- one resp. two
@@ -60,7 +59,7 @@ def test_default_headline_context_matches_oracle_across_rebinning(name, dp, DL, 
     # the configuration the headline number is measured on
     assert tun["lanes_per_particle"] == 32, tun
     assert pol["rebuild_every"] == 16, pol
-    assert sched["fuse_ea"] == 1 and sched["fuse_kgc"] == 1, sched  # two launches per step: CD, then E | A | B + clock
+    assert sched["fuse_ea"] == 1, sched
     # ... and the run went through its scheduled re-binnings (none of them forced by the drift bound)
     assert sched_after["rebins"] - sched["rebins"] == n_steps // 16 >= 1, (sched, sched_after)
     assert pol_after["forced_rebuilds"] == 0, pol_after
