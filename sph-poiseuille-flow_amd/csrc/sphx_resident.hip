@@ -224,6 +224,7 @@ namespace {
 //  no_lds_tiles: large-channel passes gather from global memory; log: forced re-binnings and timer problems on stderr)
 struct DebugSwitches {
     bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, log = false;
+    int tail_limit = 0;  // > 0: largest pass (in workgroups) whose clock update rides in pass E's tail workgroup
 };
 const DebugSwitches &debug_switches()
 {
@@ -236,10 +237,16 @@ const DebugSwitches &debug_switches()
         d.no_fuse_ea = has("no_fuse_ea");
         d.no_lds_tiles = has("no_lds_tiles");
         d.log = has("log");
+        for (int lim : {1024, 2048, 4096, 8192, 16384})
+            if (has(("tail_limit_" + std::to_string(lim)).c_str())) d.tail_limit = lim;
         return d;
     }();
     return sw;
 }
+
+// largest pass, in workgroups, whose clock update rides in a tail workgroup of pass E (and whose passes E and A share a launch)
+constexpr int kTailClockBlocks = 2048;
+int tail_clock_limit() { return debug_switches().tail_limit > 0 ? debug_switches().tail_limit : kTailClockBlocks; }
 
 thread_local sphx_ctx *g_search_ctx = nullptr;  // owns the temporary context of sphx_neighbor_search until fetch
 thread_local sphx_ctx *g_fetch_src = nullptr;   // context whose pair list the next sphx_neighbor_fetch copies out
@@ -891,7 +898,7 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->vpart.alloc(c->n_vpart);
     // Small channels with a skin: move steps are 4 launches, the clock update rides in pass E (continuity_tail);
     // vpart entries then double as "ready" flags and start out empty (all ones)
-    c->tail_clock = c->skin > 0.0 && !c->is_slab && !c->dyn && c->n_vpart <= 2048 && !debug_switches().no_tail_clock;
+    c->tail_clock = c->skin > 0.0 && !c->is_slab && !c->dyn && c->n_vpart <= tail_clock_limit() && !debug_switches().no_tail_clock;
     // (skinned slabs: the same hand-over feeds slab_seal_tail)
     const bool vpart_flags = c->tail_clock || (c->is_slab && c->rebuild_every > 1);
     SPHX_HIP(hipMemsetAsync(c->vpart.get(), vpart_flags ? 0xFF : 0, (size_t)c->n_vpart * sizeof(double), c->stream));
@@ -1115,7 +1122,7 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // dual-rate loop: a slot moves particles n_sub times as far.  Same eligibility as ctx_alloc's n_in (the fused E|A launch
     // with the clock in its tail workgroup: a skin, static schedule, <= 2048 workgroups, compact kernels)
     const bool dual_ok = c->lpp >= 16 && !c->is_slab && K > 1 && prm->dynamic_rebin != 1 &&
-                         div_up((size_t)nf * c->lpp, kBlock) <= 2048 && !debug_switches().no_tail_clock && !debug_switches().no_fuse_ea;
+                         div_up((size_t)nf * c->lpp, kBlock) <= (size_t)tail_clock_limit() && !debug_switches().no_tail_clock && !debug_switches().no_fuse_ea;
     const int n_sub = dual_ok ? dual_rate_substeps(*prm) : 1;
     if (n_sub > 1 && prm->rebuild_every <= 0) K = std::max(2, K / n_sub);
     const double d_step = 0.035 * prm->h * n_sub;

@@ -172,3 +172,26 @@ def test_one_column_channel_gives_the_nearest_image_of_every_pair(cfgmod, geom, 
     bi, bj, r = _nearest_image_pairs(parts, prm)
     assert np.array_equal(a[0].astype(int) - 1, bi) and np.array_equal(a[1].astype(int) - 1, bj)
     assert_close(a[4], r, rtol=1e-13, atol=1e-15, name="r")
+
+
+def test_tall_columns_fall_back_to_the_compact_kernels(cfgmod, geom, capi, oracle):
+    """The large-channel kernels keep fluid neighbours as 16-bit index differences, which presumes that a cell column holds
+    well under 2^15 particles.  A channel 8 000 particles high and three columns long (dp = 1.25e-4, DH = 1, DL = 12 dp) does
+    not: the automatic choice (4 lanes per particle at 96 k particles) must give way to 16 lanes and the compact kernels with
+    their 32-bit lists, an explicit request for few lanes must be refused, and the result must still be the oracle's."""
+    prm, parts = make_case(cfgmod, geom, dp=1.25e-4, DL=12 * 1.25e-4, DH=1.0, jitter=0.2, seed=5, developed=True)
+    nf, nt = parts["n_fluid"], parts["n_total"]
+    assert nf == 12 * 8000
+    args = (prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"])
+    with capi.Context(*args, t_end=1e9) as ctx:
+        assert ctx.tuning()["lanes_per_particle"] == 16, ctx.tuning()
+        assert ctx.info()["n_cell_x"] <= 4
+        st = ctx.advance(1e9, max_steps=3)
+        got = ctx.download(fields=("pos", "vel", "drho_dt", "rho"))
+    with pytest.raises(capi.SphxError) as ei:
+        capi.Context(*args, t_end=1e9, lanes_per_particle=4)
+    assert ei.value.identifier == "SPHX:Ctx:lpp"
+    ref = oracle.run(prm, parts, t_end=1e9, output_interval=1e9, max_steps=3, enable_sort=False)
+    assert st["step"] == 3 and abs(st["t"] - ref["stats"]["t"]) <= 1e-13 * ref["stats"]["t"]
+    for k in ("pos", "vel", "drho_dt", "rho"):
+        assert_close(got[k], ref[k], rtol=1e-9, atol_scale=1e-10, name=k)
