@@ -245,7 +245,9 @@ const DebugSwitches &debug_switches()
 }
 
 // largest pass, in workgroups, whose clock update rides in a tail workgroup of pass E (and whose passes E and A share a launch)
-constexpr int kTailClockBlocks = 2048;
+// Round 3: 2 048 -> 4 096.  Fusing E and A and dropping the clock launch still pays at 0.3-0.5 M particles (2 lanes: 324 k
+// 139.7 -> 129.3 us/step, C4 = 499 k 180.5 -> 172.2); at 0.83 M (6 500 workgroups) it is neutral to slightly worse (270 -> 271.5).
+constexpr int kTailClockBlocks = 4096;
 int tail_clock_limit() { return debug_switches().tail_limit > 0 ? debug_switches().tail_limit : kTailClockBlocks; }
 
 thread_local sphx_ctx *g_search_ctx = nullptr;  // owns the temporary context of sphx_neighbor_search until fetch
@@ -840,8 +842,10 @@ int pick_lpp(int nf)
     // With pass E and the next pass A in one launch and the clock in its tail (up to 2048 workgroups: 131 k particles at
     // 4 lanes, 262 k at 2) the three-launch step of 2 lanes beats the five launches of 4: 194 k particles 90.9 vs 96.4 us/step,
     // 259 k 109.1 vs 117.4; at 130 k, where both fuse, 4 lanes win (68.0 vs 70.6).
+    // Round 3 (the fused launch now reaches 4 096 workgroups = 262 k particles at 4 lanes): both lane counts fused, 4 lanes win
+    // at 151 k (76.4 vs 79.8) and 194 k (89.9 vs 90.9), 2 lanes from 259 k (110.2 vs 110.8) -> the switch moves to 220 k.
     const long target = 256L * 4 * 4 * 64;
-    if (nf > 131072) return 2;
+    if (nf > 220000) return 2;
     int lpp = 4;
     while (lpp < 32 && (long)nf * lpp * 2 <= target) lpp *= 2;
     return lpp;

@@ -19,18 +19,20 @@ pytestmark = pytest.mark.gpu
 
 FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
 #        name   dp     DL    steps  expected policy
-CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False)),
-         # 194 k particles: the largest channels whose step is three launches (2 lanes per particle, clock in the tail of E||A)
-         ("M194k", 0.01, 18.0, 10, dict(lpp=2, dynamic=False, big_scan=True)),
-         ("C4", 0.005, 12.0, 6, dict(lpp=2, dynamic=False, big_scan=True)),
-         ("C5", 0.002, 24.0, 6, dict(lpp=2, dynamic=True, big_scan=True))]
+CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False, fuse_ea=True)),
+         # 194 k particles: 4 lanes per particle up to 220 k; a step is three launches (clock in the tail of E||A) up to 4 096
+         # workgroups, i.e. at C4 too (round 3)
+         ("M194k", 0.01, 18.0, 10, dict(lpp=4, dynamic=False, big_scan=True, fuse_ea=True)),
+         ("M259k", 0.01, 24.0, 10, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True)),
+         ("C4", 0.005, 12.0, 6, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True)),
+         ("C5", 0.002, 24.0, 6, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False))]
 
 
 def _compare(name, prm, parts, n_steps, capi, oracle, expect, **ctx_kw):
     nf, nt = parts["n_fluid"], parts["n_total"]
     with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
                       t_end=1e9, **ctx_kw) as ctx:
-        info, tun, pol = ctx.info(), ctx.tuning(), ctx.grid_policy()
+        info, tun, pol, sched = ctx.info(), ctx.tuning(), ctx.grid_policy(), ctx.schedule()
         st = ctx.advance(1e9, max_steps=n_steps)
         got = ctx.download()
         tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
@@ -38,6 +40,10 @@ def _compare(name, prm, parts, n_steps, capi, oracle, expect, **ctx_kw):
     # the launch shape / grid policy this configuration is supposed to exercise
     if "lpp" in expect:
         assert tun["lanes_per_particle"] == expect["lpp"], tun
+    if "fuse_ea" in expect:
+        assert bool(sched["fuse_ea"]) == expect["fuse_ea"], sched
+    if "dynamic" in expect:
+        assert bool(sched["dynamic"]) == expect["dynamic"], sched
     if "big_scan" in expect:
         assert (info["n_cell_x"] * info["n_cell_y"] > 8192) == expect["big_scan"], info
     assert pol["rebuild_every"] < n_steps, (pol, n_steps)  # the run re-bins at least once
