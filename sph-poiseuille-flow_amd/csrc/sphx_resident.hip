@@ -848,6 +848,9 @@ int pick_lpp(int nf)
     if (nf > 220000) return 2;
     int lpp = 4;
     while (lpp < 32 && (long)nf * lpp * 2 <= target) lpp *= 2;
+    // Round 3, compact kernels with passes E and A in one launch: 32 lanes win at 1 875 fluid particles (16.1 vs 17.2 us/step),
+    // tie at 2 494, and lose from 3 300 (18.1 vs 17.5; C2 = 4 800: 19.9 vs 19.3; 5 852: 20.9 vs 19.7) -- profiles/r03_lanes_small.txt
+    if (lpp == 32 && nf > 2400) lpp = 16;
     return lpp;
 }
 

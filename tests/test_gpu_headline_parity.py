@@ -1,12 +1,12 @@
 """-m gpu: the code path behind bench.py's headline value, particle by particle against the oracle ACROSS its
 re-binnings.
 
-bench.py's C2 line runs the DEFAULT context: no lanes_per_particle, no rebuild_every -- 32 lanes per particle on the
-compact kernels, cells re-binned every 16th step (K = 16), pass E of step n and pass A of step n+1 in one launch
+bench.py's C2 line runs the DEFAULT context: no lanes_per_particle, no rebuild_every -- 16 lanes per particle (32 at C1) on
+the compact kernels, cells re-binned every 16th step (K = 16), pass E of step n and pass A of step n+1 in one launch
 (k_continuity_density, `fuse_ea`).  The other resident tests reach <= 10 steps on that context, i.e. they stop short
 of its first scheduled re-binning (step 16: k_continuity with the cell histogram -> k_clock_scan -> k_scatter ->
-k_reorder -> the stand-alone cell-sweeping k_density<32, build>).  Here C2 (dp 0.025, DL 3: 5 760 particles, the
-metric's own configuration) and C1 (dp 0.04, DL 3: config.ini's size class) run 20 and 35 steps -- one resp. two
+k_reorder -> the stand-alone cell-sweeping k_density<16, build>).  Here C2 (dp 0.025, DL 3: 5 760 particles, the
+metric's own configuration) and C1 (dp 0.04, DL 3: config.ini's size class) run 20, 35 and 100 steps -- one, two and six
 scheduled re-binnings -- and every output of the step is compared with oracle.run on the same seeded state: the
 nine fields, t, dt, max|v|, the pair count of the rebuilt neighbour structure, the wall shear.
 
@@ -28,8 +28,8 @@ pytestmark = pytest.mark.gpu
 
 FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
 RTOL = {20: 1e-10, 35: 1e-10, 100: 1e-9}
-#        name  dp     DL   lattice jitter
-CASES = [("C2", 0.025, 3.0, 0.2), ("C1", 0.04, 3.0, 0.2)]
+#        name  dp     DL   lattice jitter  lanes per particle the context picks (32 up to 2 400 fluid particles, then 16)
+CASES = [("C2", 0.025, 3.0, 0.2, 16), ("C1", 0.04, 3.0, 0.2, 32)]
 
 
 def _errors(got, ref):
@@ -43,8 +43,8 @@ def _errors(got, ref):
 
 
 @pytest.mark.parametrize("n_steps", [20, 35, 100])
-@pytest.mark.parametrize("name,dp,DL,jitter", CASES, ids=[c[0] for c in CASES])
-def test_default_headline_context_matches_oracle_across_rebinning(name, dp, DL, jitter, n_steps, cfgmod, geom, capi,
+@pytest.mark.parametrize("name,dp,DL,jitter,lanes", CASES, ids=[c[0] for c in CASES])
+def test_default_headline_context_matches_oracle_across_rebinning(name, dp, DL, jitter, lanes, n_steps, cfgmod, geom, capi,
                                                                   oracle, capsys):
     prm, parts = make_case(cfgmod, geom, dp=dp, DL=DL, jitter=jitter, seed=21, developed=True)
     nf, nt = parts["n_fluid"], parts["n_total"]
@@ -57,7 +57,7 @@ def test_default_headline_context_matches_oracle_across_rebinning(name, dp, DL, 
         tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
         pol_after, sched_after = ctx.grid_policy(), ctx.schedule()
     # the configuration the headline number is measured on
-    assert tun["lanes_per_particle"] == 32, tun
+    assert tun["lanes_per_particle"] == lanes, tun
     assert pol["rebuild_every"] == 16, pol
     assert sched["fuse_ea"] == 1, sched
     # ... and the run went through its scheduled re-binnings (none of them forced by the drift bound)
