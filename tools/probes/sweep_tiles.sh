@@ -1,9 +1,9 @@
 #!/bin/bash
 # manual sweep (not a test): LDS tile of the force pass on / off over channel sizes
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for spec in "dp=0.01,DL=9 1500" "dp=0.01,DL=12 1000" "dp=0.01,DL=18 800" "dp=0.01,DL=24 600" "dp=0.005,DL=9 400"; do
   set -- $spec
-  for v in "" "SPHX_NO_LDS_TILES=1"; do
+  for v in "" "SPHX_DEBUG_SWITCHES=no_lds_tiles"; do
     env $v timeout -k 10 200 python3 bench.py --workload $1 --steps $2 --warmup 80 --no-cpu-baseline --no-aux 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
