@@ -13,6 +13,7 @@ W = {"C2": dict(dp=0.025, DL=3.0), "C2x2": dict(dp=0.025, DL=6.0), "C3": dict(dp
 name, world, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 one_stream = "one-stream" in sys.argv[4:]
 graph = "graph" in sys.argv[4:]  # the steps replayed as one hipGraph (sphx_slab_graph_prepare)
+K = next((int(a[2:]) for a in sys.argv[4:] if a.startswith("K=")), 0)  # re-binning interval of the slabs (0 = the default)
 prm = cfg.params_from_values(end_time=1e9, **W[name])
 parts = geo.init_particles(prm)
 pos, vel = geo.developed_state(prm, parts, jitter=0.05, seed=12345)
@@ -23,7 +24,7 @@ if one_stream:
     h = ctypes.c_void_p()
     assert hip.hipStreamCreateWithFlags(ctypes.byref(h), ctypes.c_uint(1)) == 0  # hipStreamNonBlocking
     stream = h.value
-engines = [slab.HipSlabEngine(prm, parts, r, world, 0, t_end=1e9, pos=pos, vel=vel, native=True, hip_stream=stream) for r in range(world)]
+engines = [slab.HipSlabEngine(prm, parts, r, world, 0, t_end=1e9, pos=pos, vel=vel, native=True, hip_stream=stream, rebuild_every=K) for r in range(world)]
 slab.HipSlabEngine.group_run(engines, 8); [e.sync() for e in engines]
 if graph:
     slab.HipSlabEngine.graph_prepare(engines)
@@ -34,5 +35,5 @@ for e in engines: e.close()
 ctx = capi.Context(prm, parts["n_fluid"], parts["n_total"], pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9)
 ctx.enqueue_steps(40); ctx.sync()
 t0 = time.perf_counter(); ctx.enqueue_steps(steps); ctx.sync(); one = (time.perf_counter() - t0) / steps
-print(f"{name}: ring of {world} slabs on one device{' (ONE stream)' if one_stream else ''}{' (step graph)' if graph else ''} {1e6*ring:.1f} us/step, single context "
+print(f"{name}: ring of {world} slabs on one device{' (ONE stream)' if one_stream else ''}{' (step graph)' if graph else ''}{f' K={K}' if K else ''} {1e6*ring:.1f} us/step, single context "
       f"{1e6*one:.1f} us/step, ratio {ring/one:.2f}; slab 0: {lay['n_local']} particles held, capacity {lay['capacity']}")
