@@ -904,6 +904,18 @@ __device__ __forceinline__ TileMap tile_ranges(const Grid &g, const FluidSet &s,
     return tm;
 }
 
+// Tile arrays that reach a device function as plain pointer arguments (continuity_body, density_walk_body: the same bodies
+// serve kernels with and without a tile) are generic pointers to the compiler, and it read them with FLAT loads -- the texture
+// path plus an aperture check -- instead of ds_read (round 3: k_continuity<2, true, 448> at 6 M particles 415 -> 376 us once
+// told).  Read them through LDS-qualified pointers.
+using lds_f64 = const __attribute__((address_space(3))) double;
+__device__ __forceinline__ double2 lds_double2(const double2 *tile, int slot)
+{
+    lds_f64 *p = (lds_f64 *)tile;
+    return make_double2(p[2 * slot], p[2 * slot + 1]);
+}
+__device__ __forceinline__ double lds_double(const double *tile, int slot) { return ((lds_f64 *)tile)[slot]; }
+
 // tile capacity in particles: the three-column neighbourhood of kBlock / LPP particles at ~9 particles per cell
 __host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : (lpp == 4 ? 320 : 448); }
 
@@ -992,7 +1004,7 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
         if (TILE > 0) {  // positions from the tile (a few cycles away): only the entries run ahead
             auto fetch = [&](int k) -> double2 {  // (early return, not if/else: see k_kgc_w)
                 const int slot = tm.slot(k);
-                if (slot >= 0) return c_pos[slot];
+                if (slot >= 0) return lds_double2(c_pos, slot);
                 return s.pos[k];
             };
             for (int m = 0; m < rows_fl; m += 4) {
@@ -1752,7 +1764,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
         auto fetch = [&](int k, double2 &pj, double2 &vj, double &Volj) {
             if (TILE > 0) {  // (early return, not if/else: see k_kgc_w)
                 const int slot = tm.slot(k);
-                if (slot >= 0) { pj = c_pos[slot]; vj = c_vel[slot]; Volj = c_vol[slot]; return; }
+                if (slot >= 0) { pj = lds_double2(c_pos, slot); vj = lds_double2(c_vel, slot); Volj = lds_double(c_vol, slot); return; }
             }
             pj = s.pos[k]; vj = t.veln[k]; Volj = t.vol[k];
         };
