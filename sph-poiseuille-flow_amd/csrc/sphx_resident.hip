@@ -225,6 +225,7 @@ namespace {
 struct DebugSwitches {
     bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, log = false;
     int tail_limit = 0;  // > 0: largest pass (in workgroups) whose clock update rides in pass E's tail workgroup
+    int tiles_be_from = 0;  // > 0: passes B, E and A stage LDS tiles from this many resident particles (2 lanes per particle)
 };
 const DebugSwitches &debug_switches()
 {
@@ -239,6 +240,8 @@ const DebugSwitches &debug_switches()
         d.log = has("log");
         for (int lim : {1024, 2048, 4096, 8192, 16384})
             if (has(("tail_limit_" + std::to_string(lim)).c_str())) d.tail_limit = lim;
+        for (int from : {1, 250000, 500000, 750000, 1000000, 1500000, 3000000})
+            if (has(("tiles_be_from_" + std::to_string(from)).c_str())) d.tiles_be_from = from;
         return d;
     }();
     return sw;
@@ -1082,7 +1085,7 @@ void choose_kernel_forms(sphx_ctx *c, bool lpp_given, double column_load, int n_
     c->sweep_kernels = c->walk_kernels;
     c->lds_tiles = c->walk_kernels && !dbg.no_lds_tiles;  // (65 k particles: 46.8 with, 46.3 us/step without;
     // 100-130 k: equal; 194 k: 96.4 / 97.1; 259 k: 117.3 / 119.5; 360 k: 145.8 / 151.0 -- kept on at every size)
-    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= 2000000;
+    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= (dbg.tiles_be_from > 0 ? dbg.tiles_be_from : 2000000);
     c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
 }
 
