@@ -865,8 +865,14 @@ struct TileMap {
     }
     __device__ __forceinline__ int slot(int k) const  // particle -> staged slot, -1: not staged
     {
+        // three independent selects, not a nested choice: the nested form compiles to a chain of exec-mask branches (five
+        // per neighbour in the walks, with their s_nop hazards), this one to compares and v_cndmask
         const unsigned u0 = (unsigned)(k - lo0), u1 = (unsigned)(k - lo1), u2 = (unsigned)(k - lo2);
-        return u0 < (unsigned)len0 ? (int)u0 : (u1 < (unsigned)len1 ? len0 + (int)u1 : (u2 < (unsigned)len2 ? len0 + len1 + (int)u2 : -1));
+        int sl = -1;
+        sl = u2 < (unsigned)len2 ? len0 + len1 + (int)u2 : sl;
+        sl = u1 < (unsigned)len1 ? len0 + (int)u1 : sl;
+        sl = u0 < (unsigned)len0 ? (int)u0 : sl;
+        return sl;
     }
 };
 
