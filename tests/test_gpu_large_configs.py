@@ -20,6 +20,9 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
 #        name   dp     DL    steps  expected policy
 CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False, fuse_ea=True)),
+         # ... and through 26 steps of the fused large-channel launch with its 16-bit lists: at least three re-binnings (K = 8;
+         # this noisy synthetic state also outruns the skin, so a forced re-binning and its cool-down are in there as well)
+         ("C3x26", 0.01, 6.0, 26, dict(lpp=4, dynamic=False, big_scan=False, fuse_ea=True, rebins=3)),
          # 194 k particles: 4 lanes per particle up to 220 k; a step is three launches (clock in the tail of E||A) up to 4 096
          # workgroups, i.e. at C4 too (round 3)
          ("M194k", 0.01, 18.0, 10, dict(lpp=4, dynamic=False, big_scan=True, fuse_ea=True)),
@@ -37,6 +40,8 @@ def _compare(name, prm, parts, n_steps, capi, oracle, expect, **ctx_kw):
         got = ctx.download()
         tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
         pol_after = ctx.grid_policy()
+        if "rebins" in expect:
+            assert ctx.schedule()["rebins"] >= expect["rebins"], ctx.schedule()
     # the launch shape / grid policy this configuration is supposed to exercise
     if "lpp" in expect:
         assert tun["lanes_per_particle"] == expect["lpp"], tun
