@@ -25,6 +25,20 @@ def test_slab_decomposition_oracle_engine_gloo(world, DL, oracle):
     assert "OK" in r.stdout
 
 
+@pytest.mark.parametrize("fail_rank,stage", [(-1, "none"), (1, "available"), (0, "engine"), (0, "id"), (1, "init")])
+def test_ranks_agree_before_the_collective_init(fail_rank, stage):
+    """slab.join_native_ring over gloo with a stand-in C API: a rank that cannot load librccl, build its slab, make the id or
+    initialise its communicator must take every rank out with it (RuntimeError everywhere, nobody left inside the collective
+    ncclCommInitRank) -- and a healthy ring joins.  CPU only."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29571 + max(fail_rank, 0) + 3 * ["none", "available", "engine", "id", "init"].index(stage)),
+           os.path.join(ROOT, "tests", "join_worker.py"), "--fail-rank", str(fail_rank), "--stage", stage]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK") == 2, r.stdout
+
+
 def test_partition_rules():
     import importlib
     sys.path.insert(0, ROOT)
