@@ -39,6 +39,18 @@ def test_ranks_agree_before_the_collective_init(fail_rank, stage):
     assert r.stdout.count("OK") == 2, r.stdout
 
 
+def test_watchdog_ends_a_phase_that_does_not_return():
+    """bench.py --gpus N runs every potentially blocking phase under slab.Watchdog: a phase that overruns ends the process
+    with exit code 3 and says which phase it was; one that returns in time leaves no trace."""
+    code = ("import importlib, sys, time; sys.path.insert(0, %r); slab = importlib.import_module('sph-poiseuille-flow_amd.slab')\n"
+            "with slab.Watchdog('quick phase', 5.0, 0): pass\n"
+            "with slab.Watchdog('stuck collective', 0.3, 7): time.sleep(30)\n"
+            "print('not reached')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+    assert "rank 7" in r.stderr and "stuck collective" in r.stderr and "not reached" not in r.stdout
+
+
 def test_partition_rules():
     import importlib
     sys.path.insert(0, ROOT)
