@@ -4,8 +4,8 @@
  * It only unpacks mxArrays and calls libsphx (include/sphx.h).  Build (MATLAB, Linux):
  *   mex -R2018a -O -I<repo>/include -L<repo>/sph-poiseuille-flow_amd/csrc -lsphx \
  *       -output sph_neighbor_search_mex sph_neighbor_search_gateway.c
- * NOT compiled in this repository's CI: the image has no MATLAB / mex.h.  The same logic, line for line, is
- * exercised through sph-poiseuille-flow_amd/mex_surface.py.
+ * Never built with MATLAB in this repository (there is none in the image): tests/test_matlab_gateways.py compiles
+ * it against a mock of the C Matrix/MEX API (tests/stubs) and holds it to sph-poiseuille-flow_amd/mex_surface.py.
  */
 #include "mex.h"
 #include "sphx.h"

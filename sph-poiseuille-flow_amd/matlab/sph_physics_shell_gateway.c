@@ -3,9 +3,11 @@
  *   [...] = sph_physics_shell_mex(mode, ...)      8 modes, same arity / size checks / error identifiers
  * Every branch unpacks prhs[] in the reference's argument order and forwards raw column-major pointers to
  * libsphx (include/sphx.h), which runs the mode in HIP kernels.  Build like sph_neighbor_search_gateway.c with
- * -output sph_physics_shell_mex.  NOT compiled in this repository (no MATLAB / mex.h in the image); the Python
- * mirror sph-poiseuille-flow_amd/mex_surface.py carries the same checks and is what the tests drive.
+ * -output sph_physics_shell_mex.  Never built with MATLAB in this repository (there is none in the image):
+ * tests/test_matlab_gateways.py compiles it against a mock of the C Matrix/MEX API (tests/stubs) and holds it to the
+ * Python mirror sph-poiseuille-flow_amd/mex_surface.py (same checks, same identifiers, same outputs).
  */
+#include <limits.h>
 #include <string.h>
 #include "mex.h"
 #include "sphx.h"
@@ -42,9 +44,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         need(nrhs == 14, "SPH:Physics:density:nrhs", "density_correction expects 13 inputs after mode.");
         need(nlhs == 3, "SPH:Physics:density:nlhs", "density_correction expects 3 outputs.");
         np = pair_count(prhs, 7, "SPH:Physics:density:pairs", "Pair arrays mismatch.");
+        need(np <= (size_t)INT_MAX, "SPH:Physics:density:pairsize", "Pair count exceeds INT_MAX.");
         nf = (int)S(9); nt = (int)S(10);
         need(nf > 0 && nt >= nf, "SPH:Physics:density:count", "Invalid n_fluid/n_total.");
         need((int)NEL(8) == nt, "SPH:Physics:density:mass", "mass size mismatch.");
+        need(S(11) > 0.0 && S(12) > 0.0, "SPH:Physics:density:param", "rho0 and h must be positive.");
         plhs[0] = vec(nt); plhs[1] = vec(nt); plhs[2] = mat(nt, 4);
         ok(sphx_density_correction(np, D(1), D(2), D(3), D(4), D(5), D(6), D(7), D(8), nf, nt, S(11), S(12), S(13),
                                    P(plhs[0]), P(plhs[1]), P(plhs[2])));
@@ -90,8 +94,13 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         np = pair_count(prhs, 6, "SPH:Physics:pairs", "Pair arrays must have same length.");
         nf = (int)S(16); nt = (int)S(17);
 #define CHK(cond, field, msg) do { strcpy(id, "SPH:Physics:"); strcat(id, tag); strcat(id, ":" field); need(cond, id, msg); } while (0)
-        CHK((int)NEL(7) == nt, "Vol", "Vol size mismatch.");
-        CHK(IS_NX(8, nt, 4), "B", "B size mismatch.");
+        if (verlet) {       /* the two modes of the reference check these two in opposite order (:805-807 / :1345-1347) */
+            CHK((int)NEL(7) == nt, "Vol", "Vol size mismatch.");
+            CHK(IS_NX(8, nt, 4), "B", "B size mismatch.");
+        } else {
+            CHK(IS_NX(8, nt, 4), "B", "B size mismatch.");
+            CHK((int)NEL(7) == nt, "Vol", "Vol size mismatch.");
+        }
         CHK((int)NEL(9) == nt, "rho", "rho size mismatch.");
         CHK((int)NEL(10) == nt, "mass", "mass size mismatch.");
         CHK(IS_NX(11, nt, 2), "pos", "pos size mismatch.");
