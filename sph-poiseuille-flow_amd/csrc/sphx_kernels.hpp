@@ -1382,7 +1382,7 @@ struct FluidNb {
 };
 
 template <int LPP, int TILE>
-__global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                      FluidTmp t, Walls w)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
@@ -1437,6 +1437,14 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
         n.p = s.pos[k]; n.v = s.vel[k]; n.a = t.a[k]; n.B = t.B[k];
         return n;
     };
+    // The pair term, arranged for the instruction count (the pass is VALU-bound: ~70 % of its cycles issue vector
+    // instructions).  Against the reference's order of operations (sph_physics_mex.c:1100-1140), equal up to rounding:
+    //   * un_l - un_r = (v_i - v_j) . e, with the velocity difference the viscous term needs anyway;
+    //   * p_face = (p_avg + p_star) / 2 with p_star = p_avg + beta rho_bar (un_l - un_r) / 2 collapses to
+    //     (p_i + p_j) / 2 + [beta / 8] (rho_i + rho_j) (un_l - un_r); beta / 8 = min(3/8 max(du, 0), c_f / 8) exactly
+    //     (powers of two);
+    //   * mu is multiplied into the viscous sums once, after the walk.
+    const double c_f8 = 0.125 * ph.c_f;
     auto fluid_pair = [&](const FluidNb &n, double dx) {
         const double dy = yi - n.p.y;
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
@@ -1445,22 +1453,21 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
         const double tx = (b11i + n.B.x) * ex + (b12i + n.B.y) * ey;
         const double ty = (b21i + n.B.z) * ex + (b22i + n.B.w) * ey;
         const double eBe = ex * tx + ey * ty;
-        // viscous
-        const double coeff = eBe * ph.mu * dWVj * rcp_nr(r + soft);
-        ax += coeff * (vxi - n.v.x);
-        ay += coeff * (vyi - n.v.y);
+        const double dvx = vxi - n.v.x, dvy = vyi - n.v.y;
+        // viscous (without mu)
+        const double coeff = eBe * dWVj * rcp_nr(r + soft);
+        ax += coeff * dvx;
+        ay += coeff * dvy;
         // transport
         ix -= dWVj * tx;
         iy -= dWVj * ty;
         // pressure (Riemann-dissipated face pressure)
-        const double rho_bar = 0.5 * (rhoh_i + n.a.z);
-        const double un_l = vxi * ex + vyi * ey, un_r = n.v.x * ex + n.v.y * ey;
-        const double beta = riemann_beta(un_l, un_r, ph.c_f);
-        const double p_avg = 0.5 * (p_i + n.a.y);
-        const double p_star = p_avg + 0.5 * beta * rho_bar * (un_l - un_r);
-        const double p_face = 0.5 * (p_avg + p_star);
-        px -= (p_face * tx) * dWVj;
-        py -= (p_face * ty) * dWVj;
+        const double du = dvx * ex + dvy * ey;
+        const double beta8 = fmin(0.375 * fmax(du, 0.0), c_f8);
+        const double p_face = fma(beta8 * (rhoh_i + n.a.z), du, 0.5 * (p_i + n.a.y));
+        const double pw = p_face * dWVj;
+        px -= pw * tx;
+        py -= pw * ty;
     };
     if (__any(active && near_seam(g, xi)))
         walk_fluid_rows(t, tid, i, rows_fl, w0, w1, [&](int k) {
@@ -1482,14 +1489,14 @@ __global__ __launch_bounds__(kBlock) void k_forces_w(const Clock *clk, int q, Gr
         const double dWVj = spline_dW_sel(ph.kc, r) * wj.x;
         const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
         const double eBe = ex * tx + ey * ty;
-        const double coeff = 4.0 * eBe * ph.mu * dWVj * rcp_nr(r + soft);
+        const double coeff = 4.0 * eBe * dWVj * rcp_nr(r + soft);  // (mu: after the walk, see fluid_pair)
         ax += coeff * (vxi - wj.y);
         ay += coeff * (vyi - wj.z);
         ix -= 2.0 * dWVj * tx;
         iy -= 2.0 * dWVj * ty;
     });
-    ax = group_sum<LPP>(ax);
-    ay = group_sum<LPP>(ay);
+    ax = group_sum<LPP>(ax) * ph.mu;
+    ay = group_sum<LPP>(ay) * ph.mu;
     ix = group_sum<LPP>(ix);
     iy = group_sum<LPP>(iy);
     const double fpx = ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392

@@ -73,12 +73,13 @@ def periodic_bounding(pos, n_fluid, DL):
 
 
 def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_particle=0, steps_per_graph=0,
-        rebuild_every=0, restart_path=None, postprocess_path=None, dual_rate=0):
+        rebuild_every=0, restart_path=None, postprocess_path=None, dual_rate=0, mat_format="auto"):
     """Run to prm.t_end and return the final profile and L2 (SPH_Poiseuille.m:246-307 + postprocess :42).
 
     restart_path (resident engine): the reference's restart.mat protocol -- resume from it when
     prm.restart_from_file is set and its signature / sizes match (:132-163), rewrite it at every output point
-    (:295).  postprocess_path: write SPH_Poiseuille_postprocess.mat at the end (:305-306).
+    (:295).  postprocess_path: write SPH_Poiseuille_postprocess.mat at the end (:305-306).  mat_format: "7.3" (HDF5, what
+    the reference writes), "5", or "auto" = 7.3 where a libhdf5 can be loaded (restart.py); either is read back.
     dual_rate (resident engine, opt-in, NOT the reference's loop): up to that many acoustic sub-steps per outer step,
     see sphx_params.dual_rate in include/sphx.h; the result then carries n_inner and steps counts outer steps."""
     parts = init_particles(prm) if parts is None else parts
@@ -127,7 +128,7 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
                 full_profiles.append(final_profile(np.column_stack([np.mod(d["pos"][:nf, 0], prm.DL), d["pos"][:nf, 1]]),
                                                    d["vel"][:nf, 0], prm)[1])
                 if restart_path:
-                    restart.save_restart(restart_path, prm.config_signature, dict(d, t=t, step=step))
+                    restart.save_restart(restart_path, prm.config_signature, dict(d, t=t, step=step), fmt=mat_format)
                 if log:
                     log(f"output point: t={t:.6f}, step={step}")
             wall = time.perf_counter() - t0
@@ -183,7 +184,8 @@ def run(prm, engine="resident", log=None, log_every=0, parts=None, lanes_per_par
     y_mid, u_mean, u_exact = final_profile(fluid_pos, vel[:nf, 0], prm)
     if postprocess_path:
         restart.save_postprocess_data(postprocess_path, restart.make_postprocess_data(
-            prm, nf, pos, vel, n_bins, profile_times, np.column_stack([np.nan_to_num(u, nan=np.nan) for u in mid_profiles])))
+            prm, nf, pos, vel, n_bins, profile_times, np.column_stack([np.nan_to_num(u, nan=np.nan) for u in mid_profiles])),
+                                      fmt=mat_format)
     return RunResult(prm=prm, n_fluid=nf, n_total=nt, t=t, steps=int(step), wall_seconds=wall, pos=pos, vel=vel,
                      y_mid=y_mid, u_mean=u_mean, u_exact=u_exact, L2_error=l2_error(u_mean, u_exact),
                      profile_times=profile_times, mid_profile_u=mid_profiles, tau_bottom=tau_b, tau_top=tau_t,

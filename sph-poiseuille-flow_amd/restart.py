@@ -7,11 +7,13 @@ The reference writes two MAT-files at every output point / at the end of a run:
                                    SPH_Poiseuille_postprocess.m (SPH_Poiseuille.m:305-306, 612-639)
 and resumes from restart.mat when the signature string and every array size match (:132-163).
 
-The reference saves with '-v7.3' (HDF5).  This image has no HDF5 library, so the files are written here in MAT
-level 5 format (scipy.io.savemat), which MATLAB's `load` -- the call the reference uses (:133) -- reads just the
-same; files written BY the reference (v7.3) cannot be read here and `load_restart` says so instead of guessing.
-Variable names, field names, shapes ([n x 2], [n x 1] columns, scalars) and the signature string are the
-reference's, so a run of this package can be resumed or plotted by the unmodified MATLAB scripts.
+The reference saves with '-v7.3' (HDF5).  So does this module wherever a libhdf5 can be loaded (mat73.py: ctypes over
+the system library -- there is no h5py in the image, but HDF5 1.10 ships in /opt/conda/lib), and it reads what the
+reference wrote: a run started in MATLAB resumes here and the other way round.  Without the library the files are MAT
+level 5 (scipy.io.savemat), which MATLAB's `load` -- the call the reference uses (:133) -- reads just the same, and a
+v7.3 file is refused with a message that says why.  `fmt` = "7.3" | "5" | "auto" (7.3 when possible) on the writers;
+the readers look at the file.  Variable names, field names, shapes ([n x 2], [n x 1] columns, scalars) and the
+signature string are the reference's in both formats.
 """
 from __future__ import annotations
 
@@ -49,21 +51,62 @@ def make_restart_state(state: dict) -> dict:
     return out
 
 
-def save_restart(path: str, config_signature: str, state: dict) -> None:
-    """SPH_Poiseuille.m:607-610 (variables `state`, `config_signature`)."""
-    from scipy.io import savemat
+def _resolve_format(fmt: str) -> str:
+    from . import mat73
+    if fmt not in ("auto", "7.3", "5"):
+        raise RestartError(f"fmt must be 'auto', '7.3' or '5', got {fmt!r}")
+    if fmt == "auto":
+        return "7.3" if mat73.available() else "5"
+    if fmt == "7.3":
+        mat73.lib()  # raises Mat73Unavailable (a RuntimeError that names the remedy) when there is no libhdf5
+    return fmt
+
+
+def _save_mat(path: str, variables: dict, fmt: str) -> None:
+    fmt = _resolve_format(fmt)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     tmp = path + ".tmp"
-    with open(tmp, "wb") as f:  # savemat appends ".mat" to bare names; a file object keeps the name exact
-        savemat(f, {"state": make_restart_state(state), "config_signature": str(config_signature)}, format="5",
-                oned_as="column")
-    os.replace(tmp, path)  # an interrupted run never leaves half a restart file behind
+    if fmt == "7.3":
+        from . import mat73
+        mat73.save(tmp, variables)
+    else:
+        from scipy.io import savemat
+        with open(tmp, "wb") as f:  # savemat appends ".mat" to bare names; a file object keeps the name exact
+            savemat(f, variables, format="5", oned_as="column")
+    os.replace(tmp, path)  # an interrupted run never leaves half a file behind
+
+
+def save_restart(path: str, config_signature: str, state: dict, fmt: str = "auto") -> None:
+    """SPH_Poiseuille.m:607-610 (variables `state`, `config_signature`)."""
+    _save_mat(path, {"state": make_restart_state(state), "config_signature": str(config_signature)}, fmt)
 
 
 def _is_hdf5(path: str) -> bool:
-    with open(path, "rb") as f:
-        head = f.read(520)
-    return head[:8] == b"\x89HDF\r\n\x1a\n" or head[512:520] == b"\x89HDF\r\n\x1a\n"
+    from . import mat73
+    return mat73.is_mat73(path)
+
+
+def _load_mat(path: str, names) -> dict:
+    """{variable: value} with structs as dicts of arrays in MATLAB's shapes, whichever of the two formats the file has."""
+    if _is_hdf5(path):
+        from . import mat73
+        try:
+            return mat73.load(path, names)
+        except mat73.Mat73Unavailable as e:
+            raise RestartError(f"{path} is a MAT v7.3 (HDF5) file as the reference writes it, and {e}") from e
+        except mat73.Mat73Error as e:
+            raise RestartError(f"{path}: {e}") from e
+    from scipy.io import loadmat
+    raw = loadmat(path, squeeze_me=False, struct_as_record=False, variable_names=names)
+
+    def plain(v):
+        if isinstance(v, np.ndarray) and v.dtype == object and v.shape == (1, 1) and hasattr(v[0, 0], "_fieldnames"):
+            return {k: plain(getattr(v[0, 0], k)) for k in v[0, 0]._fieldnames}
+        if isinstance(v, np.ndarray) and v.dtype.kind in "US":
+            return "".join(np.asarray(v).ravel().tolist())
+        return v
+
+    return {k: plain(v) for k, v in raw.items() if not k.startswith("__")}
 
 
 def load_restart(path: str, n_total: int, config_signature: str):
@@ -71,29 +114,23 @@ def load_restart(path: str, n_total: int, config_signature: str):
     otherwise (None, reason) -- the reference prints the reason and starts from scratch."""
     if not os.path.exists(path):
         return None, "no restart file"
-    if _is_hdf5(path):
-        raise RestartError(f"{path} is a MAT v7.3 (HDF5) file as written by the reference; no HDF5 reader in this "
-                           "environment -- re-save it in MATLAB with save(..., '-v7')")
-    from scipy.io import loadmat
-    data = loadmat(path, squeeze_me=False, struct_as_record=False)
-    if "state" not in data or "config_signature" not in data:
+    data = _load_mat(path, ["state", "config_signature"])
+    if "state" not in data or "config_signature" not in data or not isinstance(data["state"], dict):
         return None, "signature mismatch"  # can_resume is false, :134-135,161
-    sig = data["config_signature"]
-    sig = "".join(np.asarray(sig).ravel().tolist()) if not isinstance(sig, str) else sig
-    if sig != config_signature:
+    if data["config_signature"] != config_signature:
         return None, "signature mismatch"
-    st = data["state"][0, 0]
+    st = data["state"]
     want = {"pos": (n_total, 2), "vel": (n_total, 2), "rho": (n_total, 1), "p": (n_total, 1), "drho_dt": (n_total, 1),
             "force": (n_total, 2), "force_prior": (n_total, 2)}
     out = {}
     for k, shape in want.items():  # valid_state, :138-146
-        if not hasattr(st, k) or tuple(np.asarray(getattr(st, k)).shape) != shape:
+        if k not in st or tuple(np.asarray(st[k]).shape) != shape:
             return None, "incompatible state"
-        out[k] = np.array(getattr(st, k), dtype=np.float64, order="F")
-    if not hasattr(st, "t") or not hasattr(st, "step"):
+        out[k] = np.array(st[k], dtype=np.float64, order="F")
+    if "t" not in st or "step" not in st:
         return None, "incompatible state"
-    out["t"] = float(np.asarray(st.t).ravel()[0])
-    out["step"] = int(round(float(np.asarray(st.step).ravel()[0])))
+    out["t"] = float(np.asarray(st["t"]).ravel()[0])
+    out["step"] = int(round(float(np.asarray(st["step"]).ravel()[0])))
     for k in ("rho", "p", "drho_dt"):
         out[k] = out[k].ravel()
     return out, None
@@ -119,9 +156,14 @@ def make_postprocess_data(prm, n_fluid: int, pos, vel, n_bins: int, profile_time
             "output": {"result_png": result_png, "profile_evolution_png": profile_evolution_png}}
 
 
-def save_postprocess_data(path: str, postprocess_data: dict) -> None:
+def save_postprocess_data(path: str, postprocess_data: dict, fmt: str = "auto") -> None:
     """SPH_Poiseuille.m:612-615 (variable `postprocess_data`)."""
-    from scipy.io import savemat
-    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    with open(path, "wb") as f:
-        savemat(f, {"postprocess_data": postprocess_data}, format="5", oned_as="column")
+    _save_mat(path, {"postprocess_data": postprocess_data}, fmt)
+
+
+def load_postprocess_data(path: str) -> dict:
+    """What SPH_Poiseuille_postprocess.m loads: the `postprocess_data` struct as nested dicts (either format)."""
+    data = _load_mat(path, ["postprocess_data"])
+    if not isinstance(data.get("postprocess_data"), dict):
+        raise RestartError(f"{path} holds no postprocess_data struct")
+    return data["postprocess_data"]

@@ -1,5 +1,8 @@
 """Restart / post-process MAT-files: same variable names, field names, shapes and
-signature rule as SPH_Poiseuille.m:132-163, 434-445, 607-639, written as MAT level 5 (readable by MATLAB's load)."""
+signature rule as SPH_Poiseuille.m:132-163, 434-445, 607-639, in the reference's own format -- MAT v7.3 (HDF5, mat73.py over
+the system's libhdf5) -- and in MAT level 5 (scipy) where no libhdf5 exists.  The v7.3 reader is pinned by a file MATLAB
+itself wrote: tests/golden/matlab_v73_testdouble.mat = scipy/io/matlab/tests/data/testhdf5_7.4_GLNX86.mat (BSD-licensed
+test datum, MATLAB 7.4 on GLNX86, one variable `testdouble` = 0:pi/4:2*pi)."""
 import importlib
 import os
 
@@ -15,6 +18,14 @@ def mods():
     return pkg.config, pkg.geometry, importlib.import_module(PKG + ".restart")
 
 
+@pytest.fixture(scope="module")
+def mat73():
+    m = importlib.import_module(PKG + ".mat73")
+    if not m.available():
+        pytest.skip("no libhdf5 on this machine")
+    return m
+
+
 def _state(n, seed=0):
     r = np.random.default_rng(seed)
     return dict(pos=r.random((n, 2)), vel=r.random((n, 2)), rho=1 + r.random(n), p=r.random(n), drho_dt=r.random(n),
@@ -27,7 +38,7 @@ def test_restart_round_trip_and_layout(mods, tmp_path):
     n = 57
     st = _state(n)
     path = str(tmp_path / "sub" / "restart.mat")
-    rst.save_restart(path, prm.config_signature, st)
+    rst.save_restart(path, prm.config_signature, st, fmt="5")
     with open(path, "rb") as f:
         assert f.read(19) == b"MATLAB 5.0 MAT-file"  # what MATLAB's load (SPH_Poiseuille.m:133) expects of a non-HDF5 file
     from scipy.io import loadmat
@@ -44,6 +55,98 @@ def test_restart_round_trip_and_layout(mods, tmp_path):
     assert got["t"] == 1.25 and got["step"] == 1234
 
 
+def test_reads_a_file_written_by_matlab(mat73):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "matlab_v73_testdouble.mat")
+    with open(path, "rb") as f:
+        head = f.read(128)
+    assert head.startswith(b"MATLAB 7.0 MAT-file, Platform: GLNX86") and b"HDF5 schema" in head and head[124:128] == b"\x00\x02IM"
+    assert mat73.is_mat73(path)
+    got = mat73.load(path)
+    assert list(got) == ["testdouble"]
+    assert got["testdouble"].shape == (1, 9)                       # a MATLAB row vector: stored with dimensions (9, 1)
+    assert np.array_equal(got["testdouble"], (np.arange(9) * (np.pi / 4)).reshape(1, 9))
+    assert mat73.load(path, names=["something_else"]) == {}
+
+
+def test_v73_files_have_matlabs_layout(mat73, tmp_path):
+    """What save(..., '-v7.3') produces, object by object (the layout mat73.py documents), and a lossless round trip."""
+    path = str(tmp_path / "x.mat")
+    v = {"a": np.arange(6.0).reshape(3, 2), "col": np.arange(4.0), "s": {"z": 1.5, "name": "abc", "none": "", "e": np.zeros((0, 2)),
+                                                                           "inner": {"k": 3, "flag": True}}, "sig": "DL=3|DH=1"}
+    mat73.save(path, v)
+    with open(path, "rb") as f:
+        head = f.read(520)
+    assert head.startswith(b"MATLAB 7.3 MAT-file, Platform: ") and b" HDF5 schema 1.00 ." in head[:116]
+    assert head[116:124] == b"\x00" * 8 and head[124:128] == b"\x00\x02IM" and head[512:520] == b"\x89HDF\r\n\x1a\n"
+    got = mat73.load(path)
+    assert set(got) == {"a", "col", "s", "sig"}
+    assert np.array_equal(got["a"], v["a"]) and got["a"].flags.f_contiguous
+    assert got["col"].shape == (4, 1) and got["sig"] == "DL=3|DH=1"
+    assert list(got["s"]) == ["z", "name", "none", "e", "inner"]                    # MATLAB_fields keeps the order
+    assert got["s"]["z"].shape == (1, 1) and got["s"]["name"] == "abc" and got["s"]["none"] == "" and got["s"]["e"].shape == (0, 2)
+    assert got["s"]["inner"]["k"][0, 0] == 3.0 and got["s"]["inner"]["flag"].dtype == bool and got["s"]["inner"]["flag"][0, 0]
+    # raw HDF5 view: dimensions reversed, class attributes (the convention the MATLAB-written fixture shows)
+    L, C = mat73.lib(), mat73.C
+    f = L.H5Fopen(path.encode(), 0, 0)
+    d = L.H5Oopen(f, b"/a", 0)
+    sp = L.H5Dget_space(d)
+    dims = (mat73.hsize_t * 2)()
+    assert L.H5Sget_simple_extent_dims(sp, dims, None) == 2 and list(dims) == [2, 3]
+    assert mat73._attr_str(d, "MATLAB_class") == "double"
+    g = L.H5Oopen(f, b"/s", 0)
+    assert mat73._attr_str(g, "MATLAB_class") == "struct" and mat73._attr_fields(g) == ["z", "name", "none", "e", "inner"]
+    c = L.H5Oopen(f, b"/sig", 0)
+    assert mat73._attr_str(c, "MATLAB_class") == "char" and L.H5Aexists(c, b"MATLAB_int_decode") > 0
+    for h in (c, g, d):
+        L.H5Oclose(h)
+    L.H5Sclose(sp); L.H5Fclose(f)
+    with pytest.raises(mat73.Mat73Error):
+        mat73.save(path, {"bad": [{"a": 1}, {"a": 2}]})                             # struct arrays / cells: not written
+
+
+@pytest.mark.parametrize("fmt", ["5", "7.3"])
+def test_both_formats_hold_the_same_restart(mods, mat73, tmp_path, fmt):
+    cfg, geo, rst = mods
+    prm = cfg.params_from_values(dp=0.05, DL=1.0)
+    n = 31
+    st = _state(n, seed=3)
+    path = str(tmp_path / f"restart_{fmt}.mat")
+    rst.save_restart(path, prm.config_signature, st, fmt=fmt)
+    assert mat73.is_mat73(path) == (fmt == "7.3")
+    raw = rst._load_mat(path, ["state", "config_signature"])
+    assert list(raw["state"]) == ["pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "t", "step"]   # :434-445
+    assert raw["state"]["rho"].shape == (n, 1) and raw["state"]["t"].shape == (1, 1) and raw["config_signature"] == prm.config_signature
+    got, why = rst.load_restart(path, n, prm.config_signature)
+    assert why is None and got["t"] == 1.25 and got["step"] == 1234
+    for k in ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior"):
+        assert np.array_equal(got[k], st[k]), k
+    assert rst.load_restart(path, n + 1, prm.config_signature) == (None, "incompatible state")
+    assert rst.load_restart(path, n, prm.config_signature + "x") == (None, "signature mismatch")
+
+
+def test_without_libhdf5_the_fallback_is_level_5_and_says_so(mods, tmp_path, monkeypatch):
+    cfg, geo, rst = mods
+    m73 = importlib.import_module(PKG + ".mat73")
+    prm = cfg.params_from_values(dp=0.05, DL=1.0)
+    have = m73.available()
+    v73 = str(tmp_path / "v73.mat")
+    if have:
+        rst.save_restart(v73, prm.config_signature, _state(8), fmt="7.3")
+    monkeypatch.setenv("SPHX_HDF5_LIB", str(tmp_path / "no_such_libhdf5.so"))
+    monkeypatch.setattr(m73, "_L", None)
+    assert not m73.available()
+    path = str(tmp_path / "auto.mat")
+    rst.save_restart(path, prm.config_signature, _state(8))                         # fmt="auto"
+    with open(path, "rb") as f:
+        assert f.read(19) == b"MATLAB 5.0 MAT-file"
+    assert rst.load_restart(path, 8, prm.config_signature)[1] is None
+    with pytest.raises(m73.Mat73Unavailable, match="libhdf5"):
+        rst.save_restart(path, prm.config_signature, _state(8), fmt="7.3")
+    if have:
+        with pytest.raises(rst.RestartError, match="libhdf5"):
+            rst.load_restart(v73, 8, prm.config_signature)
+
+
 def test_restart_is_refused_like_the_reference_refuses_it(mods, tmp_path):
     cfg, geo, rst = mods
     prm = cfg.params_from_values(dp=0.05, DL=1.0)
@@ -53,7 +156,7 @@ def test_restart_is_refused_like_the_reference_refuses_it(mods, tmp_path):
     other = cfg.params_from_values(dp=0.05, DL=1.0, end_time=7.0)          # any signature field differs -> start over (:161)
     assert rst.load_restart(path, 10, other.config_signature) == (None, "signature mismatch")
     assert rst.load_restart(path, 11, prm.config_signature) == (None, "incompatible state")   # sizes, :138-146
-    with open(str(tmp_path / "v73.mat"), "wb") as f:                        # a file as the reference writes it
+    with open(str(tmp_path / "v73.mat"), "wb") as f:                        # a truncated v7.3 file: an error, not a guess
         f.write(b"MATLAB 7.3 MAT-file".ljust(512, b" ") + b"\x89HDF\r\n\x1a\n")
     with pytest.raises(rst.RestartError):
         rst.load_restart(str(tmp_path / "v73.mat"), 10, prm.config_signature)
@@ -78,7 +181,7 @@ def test_postprocess_file_has_what_the_matlab_script_reads(mods, tmp_path):
     prof = [np.linspace(0, 1, n_bins), np.linspace(0, 2, n_bins)]
     data = rst.make_postprocess_data(prm, nf, pos, vel, n_bins, [0.0, 1.0], prof, "a.png", "b.png")
     path = str(tmp_path / "SPH_Poiseuille_postprocess.mat")
-    rst.save_postprocess_data(path, data)
+    rst.save_postprocess_data(path, data, fmt="5")
     from scipy.io import loadmat
     d = loadmat(path, squeeze_me=False, struct_as_record=False)["postprocess_data"][0, 0]
     assert d._fieldnames == ["cfg", "geom", "state", "monitor", "final_profile", "output"]           # :625-639
@@ -94,6 +197,38 @@ def test_postprocess_file_has_what_the_matlab_script_reads(mods, tmp_path):
     u_exact = prm.gravity_g / (2 * prm.nu) * fp.y_mid * (prm.DH - fp.y_mid)
     assert np.allclose(fp.u_exact, u_exact) and np.nanmax(np.abs(fp.u_mean - fp.u_exact)) < 0.02    # the parabola we fed in
     assert str(d.output[0, 0].result_png[0]) == "a.png"
+
+
+def test_postprocess_file_in_the_references_format(mods, mat73, tmp_path):
+    cfg, geo, rst = mods
+    prm = cfg.params_from_values(dp=0.05, DL=1.0)
+    parts = geo.init_particles(prm)
+    nf = parts["n_fluid"]
+    pos, vel = geo.developed_state(prm, parts, jitter=0.0, seed=1)
+    n_bins = 20
+    data = rst.make_postprocess_data(prm, nf, pos, vel, n_bins, [0.0, 1.0], [np.linspace(0, 1, n_bins), np.linspace(0, 2, n_bins)],
+                                     "a.png", "")
+    p73, p5 = str(tmp_path / "pp73.mat"), str(tmp_path / "pp5.mat")
+    rst.save_postprocess_data(p73, data, fmt="7.3")
+    rst.save_postprocess_data(p5, data, fmt="5")
+    assert mat73.is_mat73(p73) and not mat73.is_mat73(p5)
+    a, b = rst.load_postprocess_data(p73), rst.load_postprocess_data(p5)
+
+    def same(x, y, where):
+        if isinstance(x, dict):
+            assert isinstance(y, dict) and list(x) == list(y), where
+            for k in x:
+                same(x[k], y[k], where + "." + k)
+        elif isinstance(x, str):
+            assert x == y, where
+        else:
+            assert np.asarray(x).shape == np.asarray(y).shape and np.array_equal(x, y, equal_nan=True), where
+
+    same(a, b, "postprocess_data")
+    assert list(a) == ["cfg", "geom", "state", "monitor", "final_profile", "output"]            # :625-639
+    assert a["state"]["pos"].shape == (parts["n_total"], 2) and a["monitor"]["mid_profile_u"].shape == (n_bins, 2)
+    assert a["output"]["result_png"] == "a.png" and a["output"]["profile_evolution_png"] == ""
+    assert float(a["cfg"]["U_max"][0, 0]) == prm.U_max
 
 
 @pytest.mark.gpu
