@@ -68,24 +68,34 @@ __device__ __forceinline__ double spline_W(const KernelConst &kc, double r)
     return 0.0;
 }
 
-// dW/dr without branches: both polynomial pieces are evaluated (same expressions as spline_dW) and selected -- in a
-// wavefront walking neighbour lists both sides of the branch run anyway, plus the exec-mask bookkeeping.
+// dW/dr and W without branches or selects, for the large-channel walks (VALU-bound: the two-piece form cost two compares, four
+// v_cndmask and -- the compiler turned the selects back into branches -- six scalar instructions per neighbour on top of
+// both polynomials).  With a = (2 - q)+ and b = (1 - q)+ the cubic spline is ONE expression on [0, inf):
+//     W(q)  = sigma/4       [a^3 - 4 b^3]        q < 1: 1 - 1.5 q^2 + 0.75 q^3,   1 <= q < 2: 0.25 (2 - q)^3
+//     W'(q) = -0.75 sigma/h [a^2 - 4 b^2]        q < 1: -3 q + 2.25 q^2,          1 <= q < 2: -0.75 (2 - q)^2
+// -- the same polynomials as spline_dW / spline_W (sph_physics_mex.c:76-105), differently rounded (a few 1e-16 of sigma).
 __device__ __forceinline__ double spline_dW_sel(const KernelConst &kc, double r)
 {
     const double q = r * kc.inv_h;
-    const double inner = kc.sigma_over_h * (-3.0 * q + 2.25 * q * q);
-    const double tq = 2.0 - q;
-    const double outer = -kc.sigma_over_h * 0.75 * tq * tq;
-    return q < 1.0 ? inner : (q < 2.0 ? outer : 0.0);
+    const double a = fmax(2.0 - q, 0.0), b = fmax(1.0 - q, 0.0);
+    return (-0.75 * kc.sigma_over_h) * fma(-4.0 * b, b, a * a);
 }
 
+// ... for a neighbour known to lie inside the support (the step's list: pass A accepted it at these positions): no clamp of a
+// (q can exceed 2 by a rounding error: a^2 ~ 1e-31)
+__device__ __forceinline__ double spline_dW_in(const KernelConst &kc, double r)
+{
+    const double q = r * kc.inv_h;
+    const double a = 2.0 - q, b = fmax(1.0 - q, 0.0);
+    return (-0.75 * kc.sigma_over_h) * fma(-4.0 * b, b, a * a);
+}
+
+// (callers discard the value where r >= 2h: no clamp of a)
 __device__ __forceinline__ double spline_W_sel(const KernelConst &kc, double r)
 {
     const double q = r * kc.inv_h;
-    const double inner = kc.sigma * (1.0 - 1.5 * q * q + 0.75 * q * q * q);
-    const double tq = 2.0 - q;
-    const double outer = kc.sigma * 0.25 * tq * tq * tq;
-    return q < 1.0 ? inner : (q < 2.0 ? outer : 0.0);
+    const double a = 2.0 - q, b = fmax(1.0 - q, 0.0);
+    return (0.25 * kc.sigma) * fma(-4.0 * (b * b), b, (a * a) * a);
 }
 
 // 1/x for a positive normal x of moderate magnitude (here: lengths of order h): hardware estimate + two Newton steps,

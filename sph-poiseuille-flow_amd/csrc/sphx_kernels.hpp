@@ -147,6 +147,8 @@ struct FluidTmp {
     int has_slack;     // 1: the arrays hold markedly more slots than particles (slabs), see beyond_population
     double *seal_out;  // skinned slabs: the tail workgroup of pass E leaves {max |v|, max drift} of the owned particles here
                        // (the input of the step's max all-reduce), see slab_seal_tail
+    int *tmap;         // large-channel kernels: the tile layout of every workgroup (8 ints each, see tile_map_of), written by the
+                       // cell sweep at each re-binning
 };
 
 // "no value yet" in vpart when pass E carries the clock update in a tail workgroup (see continuity_tail)
@@ -316,7 +318,7 @@ __device__ __forceinline__ int delta_of_row(const int *pk, int stride, int row, 
     return (row & 1) ? delta_hi(word) : delta_lo(word);
 }
 // index difference k - i as stored (periodic grids: the representative nearest to zero modulo the population n)
-__device__ __forceinline__ int encode_delta(int k, int i, int n, bool periodic, int *flags)
+__device__ __forceinline__ int encode_delta(int k, int i, int n, bool periodic, int *flags, int limit = kDeltaMax)
 {
     int d = k - i;
     if (periodic) {
@@ -324,8 +326,25 @@ __device__ __forceinline__ int encode_delta(int k, int i, int n, bool periodic, 
         if (d > half) d -= n;
         else if (d < -half) d += n;
     }
-    if (d > kDeltaMax || d < -kDeltaMax) atomicOr(flags, 1);  // (ctx_setup keeps such grids on the compact kernels)
+    if (d > limit || d < -limit) atomicOr(flags, 1);  // (ctx_setup keeps such grids on the compact kernels)
     return d;
+}
+// Slot-coded entries (template parameter CODED of the large-channel kernels; contexts whose four passes all stage LDS tiles,
+// sphx_ctx::coded_lists).  The passes of such a context spent 13 vector instructions per neighbour turning its index into a
+// tile slot (TileMap::slot: three ranges), four times a step -- and the answer does not change between two re-binnings.
+// So the cell sweep, which runs once per re-binning, stores the answer: a 16-bit entry below kSlotCodes IS the neighbour's
+// position in the workgroup's tile layout (tile_ranges at capacity kSlotCodes: own column, left, right -- a pass with a
+// smaller tile stages a prefix of the same layout); any other value is the index difference + kCodeBias (neighbours the
+// layout does not reach: a workgroup running across a column end, ranges longer than the layout).
+constexpr int kSlotCodes = 448;
+constexpr int kCodeBias = 33000;
+constexpr int kCodedDeltaMax = 32500;  // kSlotCodes <= kCodeBias - kCodedDeltaMax,  kCodeBias + kCodedDeltaMax <= 65535
+__device__ __forceinline__ int code_lo(int word) { return word & 0xffff; }
+__device__ __forceinline__ int code_hi(int word) { return (int)((unsigned)word >> 16); }
+__device__ __forceinline__ int code_of_row(const int *pk, int stride, int row, int col)
+{
+    const int word = pk[(size_t)(row >> 1) * stride + col];
+    return (row & 1) ? code_hi(word) : code_lo(word);
 }
 // ... and back: only wavefronts near the periodic seam can hold a particle whose neighbours wrap (see near_seam)
 __device__ __forceinline__ int wrap_index(int k, int n) { return k < 0 ? k + n : (k >= n ? k - n : k); }
@@ -822,7 +841,8 @@ __device__ __forceinline__ bool near_seam(const Grid &g, double x)
 // Rows [0, rows_fl) of this lane's list column hold fluid neighbours as index differences, two rows per word (nl_pk):
 // body(i + d) for each, the words two ahead of their use (= rows 4-5 ahead).  w0 / w1: the first two words, requested by
 // the caller together with the row counts.
-template <typename Body>
+// (CODED: body(code), see kSlotCodes)
+template <bool CODED = false, typename Body>
 __device__ __forceinline__ void walk_fluid_rows(const FluidTmp &t, int tid, int i, int rows_fl, int w0, int w1, Body &&body)
 {
     if (rows_fl <= 0) return;
@@ -830,8 +850,8 @@ __device__ __forceinline__ void walk_fluid_rows(const FluidTmp &t, int tid, int 
     int wa = w0, wb = w1;
     for (int p = 0; p < n_words; ++p) {
         const int wc = p + 2 < n_words ? t.nl_pk[(size_t)(p + 2) * t.nl_stride + tid] : 0;
-        body(i + delta_lo(wa));
-        if (2 * p + 1 < rows_fl) body(i + delta_hi(wa));
+        body(CODED ? code_lo(wa) : i + delta_lo(wa));
+        if (2 * p + 1 < rows_fl) body(CODED ? code_hi(wa) : i + delta_hi(wa));
         wa = wb; wb = wc;
     }
 }
@@ -874,7 +894,50 @@ struct TileMap {
         sl = u0 < (unsigned)len0 ? (int)u0 : sl;
         return sl;
     }
+    __device__ __forceinline__ TileMap capped(int cap) const  // the first `cap` slots of the same layout
+    {
+        TileMap m = *this;
+        m.len0 = min(len0, cap);
+        m.len1 = min(len1, cap - m.len0);
+        m.len2 = min(len2, cap - m.len0 - m.len1);
+        return m;
+    }
 };
+// The layout (tile_ranges at capacity kSlotCodes) of every workgroup is worked out ONCE per re-binning, by the cell sweep, and
+// kept in FluidTmp::tmap.  Working it out in every pass put two dependent memory round trips (first / last cell of the
+// workgroup -> six cell starts) in front of the staging loads, in a prologue that already waits for the clock: the workgroups
+// of a compute unit start together and stay in step, so while they all wait nobody computes (6 M particles: a workgroup of
+// the force pass lives ~16 us, of which the vector units have work for ~9).  Read here with the workgroup's first requests.
+__device__ __forceinline__ TileMap tile_map_of(const FluidTmp &t, int blk)
+{
+    const int4 lo = reinterpret_cast<const int4 *>(t.tmap)[2 * blk], len = reinterpret_cast<const int4 *>(t.tmap)[2 * blk + 1];
+    return TileMap{lo.x, lo.y, lo.z, len.x, len.y, len.z};
+}
+__device__ __forceinline__ void store_tile_map(const FluidTmp &t, int blk, const TileMap &m)
+{
+    reinterpret_cast<int4 *>(t.tmap)[2 * blk] = make_int4(m.lo0, m.lo1, m.lo2, 0);
+    reinterpret_cast<int4 *>(t.tmap)[2 * blk + 1] = make_int4(m.len0, m.len1, m.len2, 0);
+}
+// ... cut to a pass's tile size (nothing for a workgroup beyond the population)
+template <int LPP>
+__device__ __forceinline__ TileMap staged_map(const TileMap &layout, int blk, int n_now, int cap)
+{
+    if (blk * (kBlock / LPP) >= n_now) return TileMap{0, 0, 0, 0, 0, 0};
+    return layout.capped(cap);
+}
+
+// the particle a slot-coded entry of particle i names (full: the layout at capacity kSlotCodes); the passes call this only for
+// the entries their tile does not hold
+__device__ __forceinline__ int coded_index(const TileMap &full, int code, int i, int n)
+{
+    // (slot -> particle as two independent selects on the layout's range ends, like fluid_index of the sweep: TileMap::index
+    // is a nested choice and compiles to exec-mask branches, five of them per neighbour the force pass does not stage)
+    const int n0 = full.len0, n01 = full.len0 + full.len1;
+    const int o0 = full.lo0, o1 = full.lo1 - n0, o2 = full.lo2 - n01;
+    const int k_slot = code + o2 + (code < n01 ? o1 - o2 : 0) + (code < n0 ? o0 - o1 : 0);
+    const int k_far = wrap_index(i + code - kCodeBias, n);
+    return code < kSlotCodes ? k_slot : k_far;
+}
 
 template <int LPP>
 __device__ __forceinline__ TileMap tile_ranges(const Grid &g, const FluidSet &s, int blk, int n_now, int cap)
@@ -921,6 +984,11 @@ __device__ __forceinline__ double2 lds_double2(const double2 *tile, int slot)
     return make_double2(p[2 * slot], p[2 * slot + 1]);
 }
 __device__ __forceinline__ double lds_double(const double *tile, int slot) { return ((lds_f64 *)tile)[slot]; }
+__device__ __forceinline__ double4 lds_double4(const double4 *tile, int slot)
+{
+    lds_f64 *p = (lds_f64 *)tile;
+    return make_double4(p[4 * slot], p[4 * slot + 1], p[4 * slot + 2], p[4 * slot + 3]);
+}
 
 // tile capacity in particles: the three-column neighbourhood of kBlock / LPP particles at ~9 particles per cell
 __host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : (lpp == 4 ? 320 : 448); }
@@ -932,11 +1000,13 @@ __host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : 
 // (LDS tile: staging the candidate positions makes this pass slower at 0.5 M particles -- 50.5 against 42.3 us, it gathers
 // only 16 bytes per candidate -- and, now that the pass runs at the texture addresser's limit, 6 % faster at 6 M: used
 // where KGC and continuity use theirs.)
-template <int LPP, int TILE = 0>
+// (CODED: both lists hold slot-coded entries, see kSlotCodes -- the walk copies them as they stand)
+template <int LPP, int TILE = 0, bool CODED = false>
 __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                                   const FluidTmp &t, const Walls &w, int bid, int nblk, bool half,
                                                   double2 *c_pos = nullptr)
 {
+    static_assert(!CODED || TILE == kSlotCodes, "slot-coded lists: the walk stages the whole layout");
     SPHX_PASS_INDEX_AT(bid, nblk);
     if (beyond_population<LPP>(clk, t, blk)) return;  // (nl_cnt of lanes beyond the population is never looked at)
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
@@ -944,13 +1014,14 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     const double mass_i = lead ? s.mass[i] : 1.0, drho_i = lead ? s.drho[i] : 0.0;
     const int spacked = t.sl_cnt[tid];
     const int w_first0 = t.sl_pk[tid], w_first1 = t.sl_pk[(size_t)t.nl_stride + tid];  // rows 0-3 of the packed fluid rows
+    const TileMap layout = TILE > 0 ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     const double dt = clk->dt;
     if (!clk->run[q]) return;
     const int n_now = clk->n;
     const bool active = i < n_now;
     TileMap tm{0, 0, 0, 0, 0, 0};
     if (TILE > 0) {  // candidate positions of the workgroup's three-column neighbourhood staged in LDS (see tile_ranges)
-        tm = tile_ranges<LPP>(g, s, blk, n_now, TILE);
+        tm = staged_map<LPP>(layout, blk, n_now, TILE);
         for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) c_pos[sl] = s.pos[tm.index(sl)];
         __syncthreads();
     }
@@ -1008,18 +1079,23 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
         // words: [wa wb] hold rows m .. m+3 of the current turn and the next, [wc wd] the four behind them
         int wa = w_first0, wb = w_first1, wc = word(2), wd = word(3);
         if (TILE > 0) {  // positions from the tile (a few cycles away): only the entries run ahead
-            auto fetch = [&](int k) -> double2 {  // (early return, not if/else: see k_kgc_w)
-                const int slot = tm.slot(k);
+            auto fetch = [&](int e) -> double2 {  // (early return, not if/else: see k_kgc_w)
+                if (CODED) {
+                    if (e < kSlotCodes) return lds_double2(c_pos, e);
+                    return s.pos[wrap_index(i + e - kCodeBias, n_now)];
+                }
+                const int k = index(e), slot = tm.slot(k);
                 if (slot >= 0) return lds_double2(c_pos, slot);
                 return s.pos[k];
             };
             for (int m = 0; m < rows_fl; m += 4) {
                 const int we = word((m >> 1) + 4), wf = word((m >> 1) + 5);
-                const int d0 = delta_lo(wa), d1 = delta_hi(wa), d2 = delta_lo(wb), d3 = delta_hi(wb);
-                row(d0, fetch(index(d0)));
-                if (m + 1 < rows_fl) row(d1, fetch(index(d1)));
-                if (m + 2 < rows_fl) row(d2, fetch(index(d2)));
-                if (m + 3 < rows_fl) row(d3, fetch(index(d3)));
+                const int d0 = CODED ? code_lo(wa) : delta_lo(wa), d1 = CODED ? code_hi(wa) : delta_hi(wa);
+                const int d2 = CODED ? code_lo(wb) : delta_lo(wb), d3 = CODED ? code_hi(wb) : delta_hi(wb);
+                row(d0, fetch(d0));
+                if (m + 1 < rows_fl) row(d1, fetch(d1));
+                if (m + 2 < rows_fl) row(d2, fetch(d2));
+                if (m + 3 < rows_fl) row(d3, fetch(d3));
                 wa = wc; wb = wd; wc = we; wd = wf;
             }
             return;
@@ -1058,8 +1134,8 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
                 e = t.sl_idx[(size_t)m * t.nl_stride + tid];
                 pj = w.pos[e & (kWallBit - 1)];
             } else {
-                e = delta_of_row(t.sl_pk, t.nl_stride, m, tid);
-                pj = s.pos[wrap_index(i + e, n_now)];
+                e = CODED ? code_of_row(t.sl_pk, t.nl_stride, m, tid) : delta_of_row(t.sl_pk, t.nl_stride, m, tid);
+                pj = s.pos[CODED ? coded_index(tm, e, i, n_now) : wrap_index(i + e, n_now)];
             }
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy;
@@ -1094,7 +1170,8 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
 // -- three contiguous index ranges, known before the loop -- are requested two trips ahead, the minimum-image fold runs
 // only in wavefronts near the periodic seam, the kernel value is branch-free, and kernel value and list stores are spent on
 // the candidates inside the radius only (two phases, see fluid_sweep).
-template <int LPP, int MODE>
+// (CODED: fluid entries are written slot-coded, see kSlotCodes)
+template <int LPP, int MODE, bool CODED = false>
 __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                                      const FluidTmp &t, const Walls &w, int bid, int nblk, bool half)
 {
@@ -1110,6 +1187,12 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
     const int n_now = clk->n;
     const bool active = i < n_now;
     constexpr bool record = MODE == 1;
+    // the workgroup's tile layout, the one its passes stage until the next re-binning (tile_map_of; CODED: the lists name its slots)
+    TileMap layout{0, 0, 0, 0, 0, 0};
+    if (t.tmap != nullptr) {
+        layout = tile_ranges<LPP>(g, s, blk, n_now, kSlotCodes);
+        if (threadIdx.x == 0) store_tile_map(t, blk, layout);
+    }
     double s_in = 0.0, s_ct = 0.0;
     int cnt = 0, scnt = 0;
     const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
@@ -1220,7 +1303,12 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
                 const bool acc = has && r2 < ph.kc.rcut2;
                 const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
                 s_in += acc ? W : 0.0;
-                const int d = has ? encode_delta(k, i, n_now, g.periodic != 0, t.flags) : 0;
+                int d = 0;
+                if (has) {
+                    const int slot = CODED ? layout.slot(k) : -1;
+                    d = slot >= 0 ? slot
+                                  : encode_delta(k, i, n_now, g.periodic != 0, t.flags, CODED ? kCodedDeltaMax : kDeltaMax) + (CODED ? kCodeBias : 0);
+                }
                 push_to(t.nl_idx, t.nl_pk, t.nl_cap, cnt, acc, d, false);
                 if (record) push_to(t.sl_idx, t.sl_pk, t.sl_cap, scnt, has, d, false);
                 has = has_n; k = k_n; pj = pj_n;
@@ -1276,30 +1364,31 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
 
 // n_tiles: workgroup-sized tiles of the pass; the grid may be smaller (grid-stride over the tiles: the conditional launches
 // of a dynamic context, which are idle most of the time, see launch_physics)
-template <int LPP, int MODE>
+template <int LPP, int MODE, bool CODED = false>
 __global__ __launch_bounds__(kBlock) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                             FluidTmp t, Walls w, int cond_fresh, int n_tiles)
 {
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
     for (int b = (int)blockIdx.x; b < n_tiles; b += (int)gridDim.x)
-        density_sweep_body_w<LPP, MODE>(clk, q, g, ph, s, t, w, b, n_tiles, true);
+        density_sweep_body_w<LPP, MODE, CODED>(clk, q, g, ph, s, t, w, b, n_tiles, true);
 }
 
-template <int LPP, int TILE = 0>
+template <int LPP, int TILE = 0, bool CODED = false>
 __global__ __launch_bounds__(kBlock) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                       FluidTmp t, Walls w, int cond_fresh)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots];
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
-    density_walk_body<LPP, TILE>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true, c_pos);
+    density_walk_body<LPP, TILE, CODED>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true, c_pos);
 }
 
-// pass B (see k_kgc)
-template <int LPP, int TILE>
+// pass B (see k_kgc); CODED: slot-coded list entries (kSlotCodes)
+template <int LPP, int TILE, bool CODED = false>
 __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                   FluidTmp t, Walls w, int finish_half)
 {
+    static_assert(!CODED || TILE == kSlotCodes, "slot-coded lists: this pass stages the whole layout");
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots];
     __shared__ double c_vol[kSlots];
@@ -1311,12 +1400,13 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     const double drho_own = closes ? s.drho[i] : 0.0;
     const int packed = t.nl_cnt[tid];
     const int w0 = t.nl_pk[tid], w1 = t.nl_pk[(size_t)t.nl_stride + tid];
+    const TileMap layout = TILE > 0 ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     if (!clk->run[q]) return;
     const int n_now = clk->n;
     const bool active = i < n_now;
     TileMap tm{0, 0, 0, 0, 0, 0};
     if (TILE > 0) {
-        tm = tile_ranges<LPP>(g, s, blk, n_now, TILE);
+        tm = staged_map<LPP>(layout, blk, n_now, TILE);
         for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
             const int k = tm.index(sl);
             c_pos[sl] = s.pos[k];
@@ -1338,13 +1428,32 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     auto term = [&](double dx, double dy, double Volj) {
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
         const double ex = dx * inv_r, ey = dy * inv_r;
-        const double fxj = spline_dW_sel(ph.kc, r) * Volj;
+        const double fxj = spline_dW_in(ph.kc, r) * Volj;
         a11 -= dx * (fxj * ex);
         a12 -= dx * (fxj * ey);
         a21 -= dy * (fxj * ex);
         a22 -= dy * (fxj * ey);
     };
-    if (__any(active && near_seam(g, xi)))
+    auto fetch_code = [&](int e, double2 &pj, double &Volj) {  // (CODED; early return: see above)
+        // (LDS-qualified reads: with plain ones the compiler folds both arms into FLAT loads through selected pointers)
+        if (e < kSlotCodes) { pj = lds_double2(c_pos, e); Volj = lds_double(c_vol, e); return; }
+        const int k = wrap_index(i + e - kCodeBias, n_now);
+        pj = s.pos[k]; Volj = t.vol[k];
+    };
+    const bool seam = __any(active && near_seam(g, xi));
+    if (CODED && seam)
+        walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
+            double2 pj; double Volj;
+            fetch_code(e, pj, Volj);
+            term(min_image(g, xi - pj.x), yi - pj.y, Volj);
+        });
+    else if (CODED)
+        walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
+            double2 pj; double Volj;
+            fetch_code(e, pj, Volj);
+            term(xi - pj.x, yi - pj.y, Volj);
+        });
+    else if (seam)
         walk_fluid_rows(t, tid, i, rows_fl, w0, w1, [&](int k) {
             double2 pj; double Volj;
             fetch(wrap_index(k, n_now), pj, Volj);
@@ -1381,10 +1490,12 @@ struct FluidNb {
     double4 a, B;
 };
 
-template <int LPP, int TILE>
+// (CODED: slot-coded list entries, see kSlotCodes -- this pass's tile holds the first TILE slots of the layout)
+template <int LPP, int TILE, bool CODED = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                      FluidTmp t, Walls w)
 {
+    static_assert(!CODED || (TILE > 0 && TILE <= kSlotCodes), "slot-coded lists need a tile");
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
     __shared__ double4 c_a[kSlots], c_B[kSlots];
@@ -1402,6 +1513,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     const int w0 = t.nl_pk[tid], w1 = t.nl_pk[(size_t)t.nl_stride + tid];
     const bool tracked = s.posb != nullptr;
     const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
+    const TileMap layout = TILE > 0 ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     const double dt = clk->dt;
     if (!clk->run[q]) return;
     const int n_now = clk->n;
@@ -1415,7 +1527,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 
     TileMap tm{0, 0, 0, 0, 0, 0};
     if (TILE > 0) {
-        tm = tile_ranges<LPP>(g, s, blk, n_now, TILE);
+        tm = staged_map<LPP>(layout, blk, n_now, TILE);
         for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
             const int k = tm.index(sl);
             c_pos[sl] = s.pos[k];
@@ -1425,6 +1537,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         }
         __syncthreads();
     }
+    const int n_staged = tm.total();
+    auto fetch_code = [&](int e) {  // (CODED)
+        FluidNb n;
+        if (e < n_staged) {  // (LDS-qualified reads: see k_kgc_w)
+            n.p = lds_double2(c_pos, e); n.v = lds_double2(c_vel, e); n.a = lds_double4(c_a, e); n.B = lds_double4(c_B, e);
+            return n;
+        }
+        const int k = coded_index(layout, e, i, n_now);
+        n.p = s.pos[k]; n.v = s.vel[k]; n.a = t.a[k]; n.B = t.B[k];
+        return n;
+    };
     auto fetch = [&](int k) {
         FluidNb n;
         if (TILE > 0) {  // (early return, not if/else: see k_kgc_w)
@@ -1449,7 +1572,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         const double dy = yi - n.p.y;
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
         const double ex = dx * inv_r, ey = dy * inv_r;
-        const double dWVj = spline_dW_sel(ph.kc, r) * n.a.x;
+        const double dWVj = spline_dW_in(ph.kc, r) * n.a.x;
         const double tx = (b11i + n.B.x) * ex + (b12i + n.B.y) * ey;
         const double ty = (b21i + n.B.z) * ex + (b22i + n.B.w) * ey;
         const double eBe = ex * tx + ey * ty;
@@ -1469,7 +1592,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         px -= pw * tx;
         py -= pw * ty;
     };
-    if (__any(active && near_seam(g, xi)))
+    const bool seam = __any(active && near_seam(g, xi));
+    if (CODED && seam)
+        walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
+            const FluidNb n = fetch_code(e);
+            fluid_pair(n, min_image(g, xi - n.p.x));
+        });
+    else if (CODED)
+        walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
+            const FluidNb n = fetch_code(e);
+            fluid_pair(n, xi - n.p.x);
+        });
+    else if (seam)
         walk_fluid_rows(t, tid, i, rows_fl, w0, w1, [&](int k) {
             const FluidNb n = fetch(wrap_index(k, n_now));
             fluid_pair(n, min_image(g, xi - n.p.x));
@@ -1486,7 +1620,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
         const double ex = dx * inv_r, ey = dy * inv_r;
-        const double dWVj = spline_dW_sel(ph.kc, r) * wj.x;
+        const double dWVj = spline_dW_in(ph.kc, r) * wj.x;
         const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
         const double eBe = ex * tx + ey * ty;
         const double coeff = 4.0 * eBe * dWVj * rcp_nr(r + soft);  // (mu: after the walk, see fluid_pair)
@@ -1509,7 +1643,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
-            const double dWVj = spline_dW_sel(ph.kc, r) * w.a[k].x;
+            const double dWVj = spline_dW_in(ph.kc, r) * w.a[k].x;
             const double face = -(acx * ex + acy * ey);
             const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
             const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
@@ -1723,11 +1857,13 @@ __device__ __forceinline__ void slab_seal_tail(const Clock *clk, int q, const Fl
 // tail: 1 = the launch has one workgroup more than the pass needs; it runs continuity_tail (2: slab_seal_tail)
 // WALK: the large-channel form of the walk (see the "_w" kernels): entries ahead, fluid / wall loops, fold hoisted
 // (bid, nb: this workgroup's index among the nb workgroups of the pass; c_*: the LDS tile arrays of the calling kernel)
-template <int LPP, bool WALK, int TILE>
+// CODED: slot-coded list entries (kSlotCodes)
+template <int LPP, bool WALK, int TILE, bool CODED = false>
 __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                                 const FluidTmp &t, const Walls &w, int do_hist, int tail, int bid, int nb,
                                                 double2 *c_pos, double2 *c_vel, double *c_vol, int next_half = 0)
 {
+    static_assert(!CODED || (WALK && TILE == kSlotCodes), "slot-coded lists: this pass stages the whole layout");
     const int blk = xcd_block(bid, nb);
     const int tid = blk * kBlock + threadIdx.x;
     const int i = tid / LPP, sub = tid % LPP;
@@ -1755,6 +1891,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const double4 a_own = lead ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
     const double rhoh_i = a_own.z;
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
+    const TileMap layout = (WALK && TILE > 0) ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     const double dt = clk->dt;
     if (!clk->run[q]) return;
     const int n_now = clk->n;
@@ -1765,7 +1902,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
         const int rows = active ? nn_all : 0, rows_fl = active ? list_fluid_rows(packed) : 0;
         TileMap tm{0, 0, 0, 0, 0, 0};
         if (TILE > 0) {
-            tm = tile_ranges<LPP>(g, s, blk, n_now, TILE);
+            tm = staged_map<LPP>(layout, blk, n_now, TILE);
             for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
                 const int k = tm.index(sl);
                 c_pos[sl] = s.pos[k];
@@ -1786,7 +1923,25 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
             const double ex = dx * inv_r, ey = dy * inv_r;
             rate += ((vxi - ujx) * ex + (vyi - ujy) * ey) * spline_dW_sel(ph.kc, r) * Volj;
         };
-        if (__any(active && near_seam(g, xi)))
+        auto fetch_code = [&](int e, double2 &pj, double2 &vj, double &Volj) {  // (CODED)
+            if (e < kSlotCodes) { pj = lds_double2(c_pos, e); vj = lds_double2(c_vel, e); Volj = lds_double(c_vol, e); return; }
+            const int k = wrap_index(i + e - kCodeBias, n_now);
+            pj = s.pos[k]; vj = t.veln[k]; Volj = t.vol[k];
+        };
+        const bool seam = __any(active && near_seam(g, xi));
+        if (CODED && seam)
+            walk_fluid_rows<true>(t, tid, i, rows_fl, e_row0, e_row1, [&](int e) {
+                double2 pj, vj; double Volj;
+                fetch_code(e, pj, vj, Volj);
+                term(min_image(g, xi - pj.x), yi - pj.y, vj.x, vj.y, Volj);
+            });
+        else if (CODED)
+            walk_fluid_rows<true>(t, tid, i, rows_fl, e_row0, e_row1, [&](int e) {
+                double2 pj, vj; double Volj;
+                fetch_code(e, pj, vj, Volj);
+                term(xi - pj.x, yi - pj.y, vj.x, vj.y, Volj);
+            });
+        else if (seam)
             walk_fluid_rows(t, tid, i, rows_fl, e_row0, e_row1, [&](int k) {
                 double2 pj, vj; double Volj;
                 fetch(wrap_index(k, n_now), pj, vj, Volj);
@@ -1870,7 +2025,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     }
 }
 
-template <int LPP, bool WALK, int TILE>
+template <int LPP, bool WALK, int TILE, bool CODED = false>
 __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
                                                        FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half)
 {
@@ -1883,7 +2038,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g
         else continuity_tail(clk, q, ph, t, nb);
         return;
     }
-    continuity_body<LPP, WALK, TILE>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol, next_half);
+    continuity_body<LPP, WALK, TILE, CODED>(clk, q, g, ph, s, t, w, do_hist, tail, (int)blockIdx.x, nb, c_pos, c_vel, c_vol, next_half);
 }
 
 // Small channels, steps that do not re-bin: pass E of this step and pass A of the NEXT step in one launch, side by

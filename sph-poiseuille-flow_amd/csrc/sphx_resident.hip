@@ -104,6 +104,7 @@ struct sphx_ctx {
     int n_vtiles = 0;            // > 0: k_max_tiles folds the per-block maxima first (very many blocks)
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, sl_idx, sl_cnt, flags, tile;
     DevBuf<int> nl_pk, sl_pk, nl_pk2;  // large-channel kernels: fluid entries as 16-bit index differences (FluidTmp::nl_pk)
+    DevBuf<int> tmap;                  // ... and every workgroup's tile layout (FluidTmp::tmap)
     DevBuf<double2> wpos;
     DevBuf<double4> wa;
     DevBuf<int> wid, wstart, wrow_any;
@@ -179,6 +180,7 @@ struct sphx_ctx {
     bool walk_kernels = false;   // lanes_per_particle <= 8: passes B, CD, E run their large-channel ("_w") forms
     bool lds_tiles = false;      // ... and the force pass stages its tile's neighbourhood in LDS
     bool lds_tiles_be = false;   // ... KGC and continuity too (2 lanes per particle, channel larger than the Infinity Cache)
+    bool coded_lists = false;    // ... and the lists name tile slots instead of index differences (kSlotCodes, sphx_kernels.hpp)
     bool tail_clock = false;     // move steps carry their clock update in a tail workgroup of pass E (small channels)
 
     FluidSet view(int q, int l)
@@ -219,11 +221,12 @@ struct sphx_ctx {
 namespace {
 
 // A/B switches for measurements, all behind ONE environment variable read once per process:
-//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_lds_tiles,log
+//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_lds_tiles,no_coded_lists,log
 // (no_tail_clock: the clock update as a launch of its own on every step; no_fuse_ea: passes E and A in separate launches;
-//  no_lds_tiles: large-channel passes gather from global memory; log: forced re-binnings and timer problems on stderr)
+//  no_lds_tiles: large-channel passes gather from global memory; no_coded_lists: index differences in every list, never tile
+//  slots; log: forced re-binnings and timer problems on stderr)
 struct DebugSwitches {
-    bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, log = false;
+    bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, no_coded_lists = false, log = false;
     int tail_limit = 0;  // > 0: largest pass (in workgroups) whose clock update rides in pass E's tail workgroup
     int tiles_be_from = 0;  // > 0: passes B, E and A stage LDS tiles from this many resident particles (2 lanes per particle)
 };
@@ -237,6 +240,7 @@ const DebugSwitches &debug_switches()
         d.no_tail_clock = has("no_tail_clock");
         d.no_fuse_ea = has("no_fuse_ea");
         d.no_lds_tiles = has("no_lds_tiles");
+        d.no_coded_lists = has("no_coded_lists");
         d.log = has("log");
         for (int lim : {1024, 2048, 4096, 8192, 16384})
             if (has(("tail_limit_" + std::to_string(lim)).c_str())) d.tail_limit = lim;
@@ -355,6 +359,12 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
                 // the build variant of a dynamic context is idle on four steps out of five: a grid-stride launch of an eighth
                 // of the workgroups costs an eighth to skip (6 M particles: 47 k idle workgroups were ~70 us of every step)
                 const unsigned nb = cond >= 0 ? std::max<unsigned>(1u, (unsigned)c->n_blocks_particles / 8u) : (unsigned)c->n_blocks_particles;
+                if constexpr (LPP == 2) {
+                    if (c->coded_lists) {
+                        launch(c, name, k_density_sweep_w<LPP, M, true>, dim3(nb), bp, clk, q, c->grid, c->phys, s, t, c->walls, cond, c->n_blocks_particles);
+                        return;
+                    }
+                }
                 launch(c, name, k_density_sweep_w<LPP, M>, dim3(nb), bp, clk, q, c->grid, c->phys, s, t, c->walls, cond, c->n_blocks_particles);
             };
             if (dmode == 0) sweep("k_density", std::integral_constant<int, 0>{}, -1);
@@ -362,21 +372,43 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             else {
                 const int cond = dmode == 2 ? -1 : 0;
                 if (dmode == 3) sweep("k_density_build", std::integral_constant<int, 1>{}, 1);
-                if (c->lds_tiles_a) launch(c, "k_density_walk", k_density_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+                bool done = false;
+                if constexpr (LPP == 2) {
+                    if (c->coded_lists) {
+                        launch(c, "k_density_walk", k_density_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+                        done = true;
+                    }
+                }
+                if (done) {}
+                else if (c->lds_tiles_a) launch(c, "k_density_walk", k_density_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
                 else launch(c, "k_density_walk", k_density_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
             }
         }
         // LDS tiles (tile_ranges): the force pass always; KGC and continuity where measured to pay (lds_tiles_be)
+        bool coded = false;  // slot-coded lists (2 lanes per particle, every pass with a tile): the CODED forms of the same kernels
+        if constexpr (LPP == 2) coded = c->coded_lists;
         if (!only || only == 2) {
-            if (c->lds_tiles_be) launch(c, "k_kgc", k_kgc_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
+            if constexpr (LPP == 2) {
+                if (coded) launch(c, "k_kgc", k_kgc_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
+            }
+            if (coded) {}
+            else if (c->lds_tiles_be) launch(c, "k_kgc", k_kgc_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
             else launch(c, "k_kgc", k_kgc_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
         }
         if (!only || only == 3) {
-            if (c->lds_tiles) launch(c, "k_forces", k_forces_w<LPP, (LPP <= 2 ? 320 : T)>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+            if constexpr (LPP == 2) {
+                if (coded) launch(c, "k_forces", k_forces_w<LPP, 320, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+            }
+            if (coded) {}
+            else if (c->lds_tiles) launch(c, "k_forces", k_forces_w<LPP, (LPP <= 2 ? 320 : T)>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
             else launch(c, "k_forces", k_forces_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
         }
         if (!only || only == 4) {
-            if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
+            if constexpr (LPP == 2) {
+                if (coded) launch(c, name_e, k_continuity<LPP, true, kSlotCodes, true>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
+            }
+            if (coded) {}
+            else if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
             else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
         }
     }
@@ -942,7 +974,11 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, nullptr};
+    if (c->walk_kernels) {  // (zeros = empty layouts until the first cell sweep has run)
+        c->tmap.alloc(8 * (size_t)c->n_blocks_particles); c->tmap.zero(c->stream);
+        c->tmp.tmap = c->tmap.get();
+    }
     // E|A fusion: small static-schedule channels on the compact kernels (the clock rides in the tail workgroup)
     c->fuse_ea = c->tail_clock && (c->lpp >= 16 || (c->walk_kernels && !c->lds_tiles_be && c->lpp >= 2)) && !debug_switches().no_fuse_ea;
     c->tmp_par[0] = c->tmp;
@@ -1087,6 +1123,10 @@ void choose_kernel_forms(sphx_ctx *c, bool lpp_given, double column_load, int n_
     // 100-130 k: equal; 194 k: 96.4 / 97.1; 259 k: 117.3 / 119.5; 360 k: 145.8 / 151.0 -- kept on at every size)
     c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= (dbg.tiles_be_from > 0 ? dbg.tiles_be_from : 2000000);
     c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
+    // every pass stages the same layout: the lists can name its slots (kSlotCodes) -- the index differences that remain need a
+    // little more room than the plain ones
+    static_assert(tile_slots(2) == kSlotCodes, "the layout the lists are coded against is the tile of passes A, B and E");
+    c->coded_lists = c->lds_tiles_be && c->lpp == 2 && 1.3 * column_load + 64.0 <= (double)kCodedDeltaMax && !dbg.no_coded_lists;
 }
 
 void check_lpp(int lpp)

@@ -10,9 +10,11 @@ d=json.loads(sys.stdin.read()); k=d.get('kernels_ms') or {}
 print('$1', '$3', f\"{1e3*d['ms_per_step']:.1f} us/step\", {a: round(1e3*b,1) for a,b in k.items()} if isinstance(k, dict) else '')"
 }
 for rep in 1 2 3; do
-for spec in ${SPECS:-"C4 300 40" "C5 100 40"}; do
+IFS=';' read -ra SPECLIST <<< "${SPECS:-C4 300 40;C5 100 40}"
+for spec in "${SPECLIST[@]}"; do
   set -- $spec
   run old $GRAFT_REPO_ROOT/tools/_exp/libsphx_base.so $1 $2 $3 $([ $rep = 3 ] && echo 16)
+  [ -n "$MID" ] && SPHX_DEBUG_SWITCHES=$MID run "new($MID)" "" $1 $2 $3 $([ $rep = 3 ] && echo 16)
   run new "" $1 $2 $3 $([ $rep = 3 ] && echo 16)
 done; done > $O/ab.txt 2>&1
 cat $O/ab.txt
