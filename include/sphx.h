@@ -241,6 +241,11 @@ int sphx_ctx_tuning(sphx_ctx *ctx, int *lanes_per_particle, int *steps_per_graph
  * all of them), not counting the forced ones sphx_ctx_grid_policy reports. */
 int sphx_ctx_schedule(sphx_ctx *ctx, int *fuse_ea, int *tail_clock, int *dynamic, int64_t *rebins);
 
+/* The kernel forms the context runs: walk_kernels = the large-channel ("_w") passes with 16-bit neighbour lists (up to 8
+ * lanes per particle), lds_tiles = the force pass stages its workgroup's neighbourhood in LDS, tiles_abe = passes A, B and E
+ * do too, coded_lists = the lists name tile slots instead of index differences. */
+int sphx_ctx_kernel_forms(sphx_ctx *ctx, int *walk_kernels, int *lds_tiles, int *tiles_abe, int *coded_lists);
+
 /* Inner sub-steps per step slot: 1 unless sphx_params::dual_rate asked for the dual-rate loop and the context is
  * eligible.  With n_inner > 1 a "step" of sphx_status / max_steps is an outer step (t advances by n_inner * dt_last). */
 int sphx_ctx_substeps(sphx_ctx *ctx, int *n_inner);

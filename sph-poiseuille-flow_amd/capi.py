@@ -50,7 +50,7 @@ EXPORTS = [
     "sphx_ctx_create", "sphx_ctx_destroy", "sphx_ctx_advance", "sphx_ctx_enqueue_steps", "sphx_ctx_sync",
     "sphx_ctx_prepare_steps", "sphx_ctx_graph_stats",
     "sphx_ctx_download", "sphx_ctx_monitor", "sphx_ctx_neighbor_list", "sphx_ctx_profile_enable",
-    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_substeps", "sphx_ctx_schedule", "sphx_ctx_grid_policy", "sphx_ctx_time_kernel",
+    "sphx_ctx_profile_read", "sphx_ctx_info", "sphx_ctx_tuning", "sphx_ctx_substeps", "sphx_ctx_schedule", "sphx_ctx_kernel_forms", "sphx_ctx_grid_policy", "sphx_ctx_time_kernel",
     "sphx_slab_create", "sphx_slab_layout", "sphx_slab_local_vmax", "sphx_slab_prepare", "sphx_slab_compute",
     "sphx_slab_finish", "sphx_slab_sync", "sphx_slab_snapshot", "sphx_comm_available", "sphx_comm_unique_id", "sphx_comm_selftest", "sphx_comm_selftest_graph", "sphx_slab_comm_init",
     "sphx_slab_comm_destroy", "sphx_slab_run", "sphx_slab_group_run", "sphx_slab_graph_prepare",
@@ -203,6 +203,12 @@ class Context:
         a, b, d, r = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
         check(lib().sphx_ctx_schedule(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(r)))
         return dict(fuse_ea=a.value, tail_clock=b.value, dynamic=d.value, rebins=r.value)
+
+    def kernel_forms(self):
+        """Which forms of the passes the context runs (sphx_ctx_kernel_forms)."""
+        v = [C.c_int(0) for _ in range(4)]
+        check(lib().sphx_ctx_kernel_forms(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("walk_kernels", "lds_tiles", "tiles_abe", "coded_lists"), (bool(x.value) for x in v)))
 
     def substeps(self) -> int:
         """Inner sub-steps per step slot (1 = the reference's single-rate loop, see sphx_params.dual_rate)."""

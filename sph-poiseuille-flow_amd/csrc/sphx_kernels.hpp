@@ -147,6 +147,8 @@ struct FluidTmp {
     int has_slack;     // 1: the arrays hold markedly more slots than particles (slabs), see beyond_population
     double *seal_out;  // skinned slabs: the tail workgroup of pass E leaves {max |v|, max drift} of the owned particles here
                        // (the input of the step's max all-reduce), see slab_seal_tail
+    int lazy_out;      // large-channel kernels: 1 = the output-only fields of a step (force, force_prior, rho, p) are written by the
+                       // LAST step of a batch only, see step_outputs_wanted
     int *tmap;         // large-channel kernels: the tile layout of every workgroup (8 ints each, see tile_map_of), written by the
                        // cell sweep at each re-binning
 };
@@ -259,6 +261,17 @@ __device__ __forceinline__ double next_dt(const Clock &c, const Phys &ph)
 __device__ __forceinline__ bool loop_continues(const Clock &c)
 {  // while state.t < target_time - 1e-12 (SPH_Poiseuille.m:250) and step budget left
     return (c.t < c.t_target - 1e-12) && (c.steps_left != 0) && (c.status == 0) && (c.need_rebuild == 0);
+}
+
+// force, force_prior (pass CD) and rho, p (pass E) are results for the caller: no later step reads them (the next pass A sums
+// the density afresh, the next pass CD builds both forces from scratch), and they are 48 of the ~650 bytes a large-channel
+// step moves per particle.  Contexts with FluidTmp::lazy_out write them only in the step after which the batch stops --
+// the step budget's last step, or the one that reaches the target time -- which is the only state a caller can look at.
+// (The clock still holds the state BEFORE this step while its passes run: clock_step comes after pass E.)
+__device__ __forceinline__ bool step_outputs_wanted(const Clock *clk, const FluidTmp &t)
+{
+    if (!t.lazy_out) return true;
+    return clk->steps_left == 1 || !(clk->t + clk->dt < clk->t_target - 1e-12);  // (the test of loop_continues, a step early)
 }
 
 // Kernels of the re-binning chain take the slot parity with a flag: bit 1 set = "only when the clock says
@@ -1515,6 +1528,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
     const TileMap layout = TILE > 0 ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     const double dt = clk->dt;
+    const bool want_out = step_outputs_wanted(clk, t);
     if (!clk->run[q]) return;
     const int n_now = clk->n;
     const bool active = i < n_now;
@@ -1675,8 +1689,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         if (g.periodic) xo = xo >= ph.DL ? xo - ph.DL : (xo < 0.0 ? xo + ph.DL : xo);
         t.posn[i] = make_double2(xo, yo);
         t.veln[i] = make_double2(vxn, vyn);
-        t.fp[i] = make_double2(fpx, fpy);
-        t.f[i] = make_double2(fx, fy);
+        if (want_out) {
+            t.fp[i] = make_double2(fpx, fpy);
+            t.f[i] = make_double2(fx, fy);
+        }
     }
     // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
 #pragma unroll
@@ -1893,6 +1909,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
     const TileMap layout = (WALK && TILE > 0) ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     const double dt = clk->dt;
+    const bool want_out = !WALK || step_outputs_wanted(clk, t);
     if (!clk->run[q]) return;
     const int n_now = clk->n;
     const bool active = i < n_now;
@@ -1988,8 +2005,10 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
         double rho = rhoh + drho_new * (0.5 * dt);
         if (rho < 1e-10) rho = ph.rho0;
         t.drhon[i] = drho_new;
-        t.rho_out[i] = rho;
-        t.p_out[i] = eos_pressure(rho, ph.rho0, ph.p0);
+        if (want_out) {
+            t.rho_out[i] = rho;
+            t.p_out[i] = eos_pressure(rho, ph.rho0, ph.p0);
+        }
         if (next_half) {  // dual-rate loop: another sub-step follows, with the density carried on (not re-summed)
             double rhoh2, p2;
             half_state(ph, rho, drho_new, dt, rhoh2, p2);

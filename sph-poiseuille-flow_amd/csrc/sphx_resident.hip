@@ -221,12 +221,13 @@ struct sphx_ctx {
 namespace {
 
 // A/B switches for measurements, all behind ONE environment variable read once per process:
-//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_lds_tiles,no_coded_lists,log
+//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_lds_tiles,no_coded_lists,no_lazy_out,log
 // (no_tail_clock: the clock update as a launch of its own on every step; no_fuse_ea: passes E and A in separate launches;
 //  no_lds_tiles: large-channel passes gather from global memory; no_coded_lists: index differences in every list, never tile
-//  slots; log: forced re-binnings and timer problems on stderr)
+//  slots; no_lazy_out: force, force_prior, rho, p written by every step (FluidTmp::lazy_out); log: forced re-binnings and timer
+//  problems on stderr)
 struct DebugSwitches {
-    bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, no_coded_lists = false, log = false;
+    bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, no_coded_lists = false, no_lazy_out = false, log = false;
     int tail_limit = 0;  // > 0: largest pass (in workgroups) whose clock update rides in pass E's tail workgroup
     int tiles_be_from = 0;  // > 0: passes B, E and A stage LDS tiles from this many resident particles (2 lanes per particle)
 };
@@ -241,6 +242,7 @@ const DebugSwitches &debug_switches()
         d.no_fuse_ea = has("no_fuse_ea");
         d.no_lds_tiles = has("no_lds_tiles");
         d.no_coded_lists = has("no_coded_lists");
+        d.no_lazy_out = has("no_lazy_out");
         d.log = has("log");
         for (int lim : {1024, 2048, 4096, 8192, 16384})
             if (has(("tail_limit_" + std::to_string(lim)).c_str())) d.tail_limit = lim;
@@ -974,7 +976,10 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, nullptr};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, 0, nullptr};
+    // (slabs run their own loop, one batch per step; the dual-rate loop, which reads force_prior in its inner sub-steps, runs
+    //  on the compact kernels only)
+    c->tmp.lazy_out = (c->walk_kernels && !c->is_slab && !debug_switches().no_lazy_out) ? 1 : 0;
     if (c->walk_kernels) {  // (zeros = empty layouts until the first cell sweep has run)
         c->tmap.alloc(8 * (size_t)c->n_blocks_particles); c->tmap.zero(c->stream);
         c->tmp.tmap = c->tmap.get();
@@ -1121,7 +1126,9 @@ void choose_kernel_forms(sphx_ctx *c, bool lpp_given, double column_load, int n_
     c->sweep_kernels = c->walk_kernels;
     c->lds_tiles = c->walk_kernels && !dbg.no_lds_tiles;  // (65 k particles: 46.8 with, 46.3 us/step without;
     // 100-130 k: equal; 194 k: 96.4 / 97.1; 259 k: 117.3 / 119.5; 360 k: 145.8 / 151.0 -- kept on at every size)
-    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= (dbg.tiles_be_from > 0 ? dbg.tiles_be_from : 2000000);
+    // (round 3, layouts stored + slot-coded lists: 0.5 M 164 without / 175 us/step with -- it gives up the fused E|A launch --,
+    //  0.83 M 260 / 260, 1.3 M 430 / 420; before that: 270 / 285 at 0.83 M, 440 / 457 at 1.3 M, hence 2 M then)
+    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= (dbg.tiles_be_from > 0 ? dbg.tiles_be_from : 1000000);
     c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
     // every pass stages the same layout: the lists can name its slots (kSlotCodes) -- the index differences that remain need a
     // little more room than the plain ones
@@ -1682,6 +1689,18 @@ SPHX_EXPORT int sphx_ctx_schedule(sphx_ctx *c, int *fuse_ea, int *tail_clock, in
     if (tail_clock) *tail_clock = c->tail_clock ? 1 : 0;
     if (dynamic) *dynamic = c->dyn ? 1 : 0;
     if (rebins) *rebins = c->dyn ? (int64_t)c->h_clock->n_rebins : c->n_rebins;
+    return SPHX_OK;
+    SPHX_CATCH
+}
+
+SPHX_EXPORT int sphx_ctx_kernel_forms(sphx_ctx *c, int *walk_kernels, int *lds_tiles, int *tiles_abe, int *coded_lists)
+{
+    SPHX_TRY
+    require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    if (walk_kernels) *walk_kernels = c->walk_kernels ? 1 : 0;
+    if (lds_tiles) *lds_tiles = c->lds_tiles ? 1 : 0;
+    if (tiles_abe) *tiles_abe = c->lds_tiles_be ? 1 : 0;
+    if (coded_lists) *coded_lists = c->coded_lists ? 1 : 0;
     return SPHX_OK;
     SPHX_CATCH
 }

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 FIELDS = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
 #        name   dp     DL    steps  expected policy
-CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False, fuse_ea=True)),
+CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False, fuse_ea=True, forms=dict(walk_kernels=True, lds_tiles=True, tiles_abe=False, coded_lists=False))),
          # ... and through 26 steps of the fused large-channel launch with its 16-bit lists: at least three re-binnings (K = 8;
          # this noisy synthetic state also outruns the skin, so a forced re-binning and its cool-down are in there as well)
          ("C3x26", 0.01, 6.0, 26, dict(lpp=4, dynamic=False, big_scan=False, fuse_ea=True, rebins=3)),
@@ -27,15 +27,18 @@ CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False, fuse_e
          # workgroups, i.e. at C4 too (round 3)
          ("M194k", 0.01, 18.0, 10, dict(lpp=4, dynamic=False, big_scan=True, fuse_ea=True)),
          ("M259k", 0.01, 24.0, 10, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True)),
-         ("C4", 0.005, 12.0, 6, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True)),
-         ("C5", 0.002, 24.0, 6, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False))]
+         ("C4", 0.005, 12.0, 6, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True, forms=dict(tiles_abe=False, coded_lists=False))),
+         # from 10^6 particles every pass stages an LDS tile and the lists name tile slots (slot-coded, round 3): the smallest
+         # such channel and the largest configuration
+         ("M1250k", 0.004, 20.0, 6, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True))),
+         ("C5", 0.002, 24.0, 6, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True)))]
 
 
 def _compare(name, prm, parts, n_steps, capi, oracle, expect, **ctx_kw):
     nf, nt = parts["n_fluid"], parts["n_total"]
     with capi.Context(prm, nf, nt, parts["pos"], parts["vel"], parts["drho_dt"], parts["mass"], parts["wall_vel"],
                       t_end=1e9, **ctx_kw) as ctx:
-        info, tun, pol, sched = ctx.info(), ctx.tuning(), ctx.grid_policy(), ctx.schedule()
+        info, tun, pol, sched, forms = ctx.info(), ctx.tuning(), ctx.grid_policy(), ctx.schedule(), ctx.kernel_forms()
         st = ctx.advance(1e9, max_steps=n_steps)
         got = ctx.download()
         tb, tt, npairs = ctx.monitor(tau=True, pairs=True)
@@ -45,6 +48,8 @@ def _compare(name, prm, parts, n_steps, capi, oracle, expect, **ctx_kw):
     # the launch shape / grid policy this configuration is supposed to exercise
     if "lpp" in expect:
         assert tun["lanes_per_particle"] == expect["lpp"], tun
+    for k, v in expect.get("forms", {}).items():
+        assert forms[k] == v, (k, forms)
     if "fuse_ea" in expect:
         assert bool(sched["fuse_ea"]) == expect["fuse_ea"], sched
     if "dynamic" in expect:
