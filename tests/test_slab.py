@@ -89,6 +89,7 @@ def test_slab_hip_two_ranks_half_million_particles():
     (2, 0.04, 3.0, 17, dict(rebuild_every=8, skin_h=0.05)),  # skin far too thin: the drift bound triggers the re-binnings
     (4, 0.01, 6.0, 12, dict()),
     (2, 0.005, 12.0, 7, dict()),                             # 0.25 M particles per slab: multi-block scan, 2 lanes per particle
+    (2, 0.004, 40.0, 7, dict()),                             # 1.25 M per slab: LDS tiles in every pass, slot-coded lists, stored tile layouts
     # the steps as ONE replayed hipGraph (sphx_slab_graph_prepare: ten steps per replay, kernels + copies + cross-stream
     # dependencies captured): prepared after the first call; 25 = two replays + five eager steps, and the last call finds
     # the other state parity -> eager again

@@ -16,10 +16,10 @@ bash tools/probes/profile_pmc.sh C2 0 200 ${TAG}f > $OUT/pmc_c2.log 2>&1; echo "
 bash tools/probes/profile_pmc.sh C5 0 10 ${TAG}f "--dynamic 2" > $OUT/pmc_c5.log 2>&1; echo "pmc C5 done"
 for a in "C5 8 40" "C5 2 40" "C4 2 100" "C2 2 400" "C5 8 40 one-stream" "C4 2 100 graph" "C2 2 400 graph"; do python tools/probes/probe_slab_ring.py $a; done 2>&1 | grep -v amdgpu.ids | tee $OUT/slab_ring.txt
 python tools/probes/probe_short_batch.py 2>&1 | grep -v amdgpu.ids | tee $OUT/short_batch.txt
-python - <<'PY'
-import json
+TAG=$TAG python - <<'PY'
+import json, os
 for f in ("bench", "bench_driver_style"):
-    d = json.load(open(f"gpurun_out/final_r3/{f}.json"))
+    d = json.load(open(f"gpurun_out/final_{os.environ['TAG']}/{f}.json"))
     print(f, f"{d['value']:.4e}", f"{1e3*d['ms_per_step']:.2f} us/step", "roof", d["roofline"]["kernel"], round(d["roofline"]["frac"], 4))
     for k, a in (d.get("aux") or {}).items():
         if "value" in a: print("  aux", k, f"{a['value']:.4e}", f"{1e3*a['ms_per_step']:.1f} us/step", "sustained", a.get("sustained") and f"{a['sustained']['value']:.4e}")
