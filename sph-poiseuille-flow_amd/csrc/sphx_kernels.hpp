@@ -148,7 +148,7 @@ struct FluidTmp {
     double *seal_out;  // skinned slabs: the tail workgroup of pass E leaves {max |v|, max drift} of the owned particles here
                        // (the input of the step's max all-reduce), see slab_seal_tail
     int lazy_out;      // large-channel kernels: 1 = the output-only fields of a step (force, force_prior, rho, p) are written by the
-                       // LAST step of a batch only, see step_outputs_wanted
+                       // LAST step of a batch only, 2 = never, see step_outputs_wanted
     int *tmap;         // large-channel kernels: the tile layout of every workgroup (8 ints each, see tile_map_of), written by the
                        // cell sweep at each re-binning
 };
@@ -271,6 +271,7 @@ __device__ __forceinline__ bool loop_continues(const Clock &c)
 __device__ __forceinline__ bool step_outputs_wanted(const Clock *clk, const FluidTmp &t)
 {
     if (!t.lazy_out) return true;
+    if (t.lazy_out == 2) return false;  // (a slab: nobody can ask for them, sphx_slab_snapshot hands out the state only)
     return clk->steps_left == 1 || !(clk->t + clk->dt < clk->t_target - 1e-12);  // (the test of loop_continues, a step early)
 }
 

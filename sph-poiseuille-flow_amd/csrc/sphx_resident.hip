@@ -977,9 +977,9 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
                       c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, 0, nullptr};
-    // (slabs run their own loop, one batch per step; the dual-rate loop, which reads force_prior in its inner sub-steps, runs
-    //  on the compact kernels only)
-    c->tmp.lazy_out = (c->walk_kernels && !c->is_slab && !debug_switches().no_lazy_out) ? 1 : 0;
+    // (2 = never: a slab hands out its state only, sphx_slab_snapshot; the dual-rate loop, which reads force_prior in its
+    //  inner sub-steps, runs on the compact kernels only)
+    c->tmp.lazy_out = (c->walk_kernels && !debug_switches().no_lazy_out) ? (c->is_slab ? 2 : 1) : 0;
     if (c->walk_kernels) {  // (zeros = empty layouts until the first cell sweep has run)
         c->tmap.alloc(8 * (size_t)c->n_blocks_particles); c->tmap.zero(c->stream);
         c->tmp.tmap = c->tmap.get();

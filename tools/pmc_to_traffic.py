@@ -25,7 +25,7 @@ def main():
         first = next((k for k, x in enumerate(tok) if "=" in x), len(tok))
         name, kv = " ".join(tok[:first]), tok[first:]
         # pass A variants: 0 sweep, 1 sweep + superset list, 2 walk (k_density_sweep_w: the large-channel form of 0 / 1)
-        mode = re.search(r"k_density(?:_sweep_w)?<\d+,\s*(\d)>", name)
+        mode = re.search(r"k_density(?:_sweep_w)?<\d+,\s*(\d)[,>]", name)
         name = re.sub(r"<.*", "", name)
         if mode:
             name += {"0": "", "1": "_build", "2": "_walk"}[mode.group(1)]
