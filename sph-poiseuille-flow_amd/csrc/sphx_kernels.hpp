@@ -211,6 +211,9 @@ __device__ __forceinline__ bool duplicate_column(const Grid &g, int ox)
     return (g.ncx == 1 && ox != 0) || (g.ncx == 2 && ox == 1);
 }
 
+// the value of the other lane of a pair (lanes 2k, 2k + 1): one DPP move (quad_perm [1 0 3 2]), no LDS crossbar, no ballot
+__device__ __forceinline__ int pair_partner(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+
 template <int LPP>
 __device__ __forceinline__ double group_sum(double v)
 {
@@ -322,7 +325,7 @@ __device__ __forceinline__ int list_fluid_rows(int packed) { return packed >> 16
 constexpr int kDeltaMax = 32767;
 __device__ __forceinline__ void put_delta(int *pk, int stride, int row, int col, int d)
 {
-    reinterpret_cast<short *>(pk)[((size_t)(row >> 1) * stride + col) * 2 + (row & 1)] = (short)d;
+    reinterpret_cast<short *>(pk)[((size_t)((unsigned)row >> 1) * (unsigned)stride + (unsigned)col) * 2 + ((unsigned)row & 1u)] = (short)d;
 }
 __device__ __forceinline__ int delta_lo(int word) { return (int)(short)(word & 0xffff); }
 __device__ __forceinline__ int delta_hi(int word) { return word >> 16; }
@@ -1052,16 +1055,28 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     int cnt = 0;
     // the step's list takes the candidate's entry as it stands in the superset list: a fluid entry is the index difference to
     // THIS particle in both, a wall entry the wall slot
+    // (2 lanes per particle: who else accepts is one DPP move away -- the ballot, the half select, the shift and the two
+    //  popcounts were 9 of the ~55 vector instructions of a candidate in a pass that is ALU-bound; unsigned row arithmetic:
+    //  m / LPP on a signed m costs a sign fix-up per use)
     auto push = [&](bool acc, int entry, bool wall) {
-        const unsigned grp = LPP == 1 ? (acc ? 1u : 0u) : group_bits(acc);
+        int below, all;
+        if constexpr (LPP == 2) {
+            const int mine = acc ? 1 : 0, other = pair_partner(mine);
+            below = sub ? other : 0;
+            all = mine + other;
+        } else {
+            const unsigned grp = LPP == 1 ? (acc ? 1u : 0u) : group_bits(acc);
+            below = __popc(grp & below_me);
+            all = __popc(grp);
+        }
         if (acc) {
-            const int m = cnt + __popc(grp & below_me);
-            if (m / LPP < t.nl_cap) {
-                if (wall) t.nl_idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
-                else put_delta(t.nl_pk, t.nl_stride, m / LPP, row_base + (m % LPP), entry);
+            const unsigned m = (unsigned)(cnt + below), row = m / LPP, col = (unsigned)row_base + m % LPP;
+            if ((int)row < t.nl_cap) {
+                if (wall) t.nl_idx[(size_t)row * t.nl_stride + col] = entry;
+                else put_delta(t.nl_pk, t.nl_stride, (int)row, (int)col, entry);
             }
         }
-        cnt += __popc(grp);
+        cnt += all;
     };
     const int ns = active ? list_rows(spacked) : 0;
     // group-uniform trip counts: lane 0 of the group owns the most rows, its last lane the fewest fluid rows
@@ -1220,16 +1235,25 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
         return (half_ >> half_shift) & grp_mask;
     };
     // fluid entries go to the packed list as index differences to this group's particle, wall entries to the 32-bit one
-    auto push_to = [&](int *idx, int *pk, int cap, int &n, bool acc, int entry, bool wall) {
-        const unsigned grp = LPP == 1 ? (acc ? 1u : 0u) : group_bits(acc);
+    auto push_to = [&](int *idx, int *pk, int cap, int &n, bool acc, int entry, bool wall) {  // (see push of density_walk_body)
+        int below, all;
+        if constexpr (LPP == 2) {
+            const int mine = acc ? 1 : 0, other = pair_partner(mine);
+            below = sub ? other : 0;
+            all = mine + other;
+        } else {
+            const unsigned grp = LPP == 1 ? (acc ? 1u : 0u) : group_bits(acc);
+            below = __popc(grp & below_me);
+            all = __popc(grp);
+        }
         if (acc) {
-            const int m = n + __popc(grp & below_me);
-            if (m / LPP < cap) {
-                if (wall) idx[(size_t)(m / LPP) * t.nl_stride + row_base + (m % LPP)] = entry;
-                else put_delta(pk, t.nl_stride, m / LPP, row_base + (m % LPP), entry);
+            const unsigned m = (unsigned)(n + below), row = m / LPP, col = (unsigned)row_base + m % LPP;
+            if ((int)row < cap) {
+                if (wall) idx[(size_t)row * t.nl_stride + col] = entry;
+                else put_delta(pk, t.nl_stride, (int)row, (int)col, entry);
             }
         }
-        n += __popc(grp);
+        n += all;
     };
     const double xi = pi.x, yi = pi.y;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
