@@ -1412,7 +1412,7 @@ __global__ __launch_bounds__(kBlock) void k_density_sweep_w(const Clock *clk, in
 }
 
 template <int LPP, int TILE = 0, bool CODED = false>
-__global__ __launch_bounds__(kBlock) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((TILE > 0 || LPP <= 2) ? 8 : 1))) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                       FluidTmp t, Walls w, int cond_fresh)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
@@ -2069,8 +2069,11 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     }
 }
 
+// (waves_per_eu: the large-channel forms of passes E and A fit eight waves per SIMD by their vector registers (62-67) but took 106
+//  scalar registers -- seven waves; they are latency-bound, the eighth wave is worth 9 % of pass E at 6 M particles.  Asked for,
+//  the compiler finds a 78-SGPR allocation without spills.)
 template <int LPP, bool WALK, int TILE, bool CODED = false>
-__global__ __launch_bounds__(kBlock) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WALK ? 8 : 1))) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
                                                        FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
@@ -2108,7 +2111,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity_density(Clock *clk, int q
 
 // the same with the large-channel forms of the two passes (mid-size channels: 4-8 lanes per particle, clock in the tail)
 template <int LPP>
-__global__ __launch_bounds__(kBlock) void k_continuity_density_w(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8))) void k_continuity_density_w(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
                                                                  Walls w, FluidSet s_next, FluidTmp t_next, int with_tail)
 {
     const int nb = ((int)gridDim.x - with_tail) / 2;  // (with_tail = 0: kernel timing, the clock must not advance)
