@@ -214,11 +214,36 @@ __device__ __forceinline__ bool duplicate_column(const Grid &g, int ox)
 // the value of the other lane of a pair (lanes 2k, 2k + 1): one DPP move (quad_perm [1 0 3 2]), no LDS crossbar, no ballot
 __device__ __forceinline__ int pair_partner(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 
+// Sum over the LPP lanes of a particle, in every lane.  Up to 16 lanes a group lies in one DPP row: two quad permutes
+// (lane ^ 1, lane ^ 2), row_half_mirror and row_mirror pair every lane with one that holds the other part -- two v_mov_dpp
+// and an add per stage, where __shfl_xor is two ds_bpermute through the LDS crossbar and a wait (a pass of the small
+// channels ends with four to seven such sums, four stages each, all on its critical path).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// max over the wave of non-negative values (squares), in every lane: four DPP stages inside the rows, two crossbar stages across
+__device__ __forceinline__ double wave_max(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    v = fmax(v, __shfl_xor(v, 16));
+    return fmax(v, __shfl_xor(v, 32));
+}
 template <int LPP>
 __device__ __forceinline__ double group_sum(double v)
 {
+    if (LPP >= 2) v += dpp_f64<0xB1>(v);    // quad_perm [1 0 3 2]
+    if (LPP >= 4) v += dpp_f64<0x4E>(v);    // quad_perm [2 3 0 1]
+    if (LPP >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
+    if (LPP >= 16) v += dpp_f64<0x140>(v);  // row_mirror
 #pragma unroll
-    for (int off = LPP / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    for (int off = LPP / 2; off >= 16; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
 
@@ -471,7 +496,7 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                         acc = true;
-                        const double W = spline_W(ph.kc, r2 * rsqrt(r2));
+                        const double W = spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
                         if (wall) s_ct += W * Volw;
                         else s_in += W;
                     }
@@ -530,7 +555,7 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
                 const double r2 = dx * dx + dy * dy;
                 if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                     acc = true;
-                    s_in += spline_W(ph.kc, r2 * rsqrt(r2));
+                    s_in += spline_W_sel(ph.kc, r2 * rsqrt_nr(r2));
                 }
                 wide = r2 > kR2Min && r2 < t.sl_rcut2;
             }
@@ -554,7 +579,7 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
                     const double r2 = dx * dx + dy * dy;
                     if (r2 > kR2Min && r2 < ph.kc.rcut2) {
                         acc = true;
-                        s_ct += spline_W(ph.kc, r2 * rsqrt(r2)) * Volj;
+                        s_ct += spline_W_sel(ph.kc, r2 * rsqrt_nr(r2)) * Volj;
                     }
                     wide = r2 > kR2Min && r2 < t.sl_rcut2;
                 }
@@ -640,9 +665,9 @@ __global__ __launch_bounds__(kBlock) void k_kgc(const Clock *clk, int q, Grid g,
             const double2 pj = (wall ? w.pos : (const double2 *)s.pos)[k];
             const double Volj = wall ? w.a[k].x : t.vol[k];
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-            const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
-            const double fxj = spline_dW(ph.kc, r) * Volj;
+            const double fxj = spline_dW_in(ph.kc, r) * Volj;
             a11 -= dx * (fxj * ex);
             a12 -= dx * (fxj * ey);
             a21 -= dy * (fxj * ex);
@@ -713,9 +738,9 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
                 const double2 pj = s.pos[k], vj = s.vel[k];
                 const double4 aj = t.a[k], Bj = t.B[k];
                 const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-                const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
+                const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
                 const double ex = dx * inv_r, ey = dy * inv_r;
-                const double dW = spline_dW(ph.kc, r);
+                const double dW = spline_dW_in(ph.kc, r);
                 const double Volj = aj.x;
                 const double tx = (b11i + Bj.x) * ex + (b12i + Bj.y) * ey;
                 const double ty = (b21i + Bj.z) * ex + (b22i + Bj.w) * ey;
@@ -724,7 +749,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
                 const double dWVj = dW * Volj;
                 if (!later) {
                     // viscous
-                    const double coeff = eBe * ph.mu * dWVj / (r + 0.01 * h);
+                    const double coeff = eBe * ph.mu * dWVj * rcp_nr(r + 0.01 * h);
                     ax += coeff * (vxi - vxj);
                     ay += coeff * (vyi - vyj);
                     // transport
@@ -747,12 +772,12 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
                 const double2 pj = w.pos[k];
                 const double4 wj = w.a[k];
                 const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-                const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
+                const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
                 const double ex = dx * inv_r, ey = dy * inv_r;
-                const double dWVj = spline_dW(ph.kc, r) * wj.x;
+                const double dWVj = spline_dW_in(ph.kc, r) * wj.x;
                 const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
                 const double eBe = ex * tx + ey * ty;
-                const double coeff = 4.0 * eBe * ph.mu * dWVj / (r + 0.01 * h);
+                const double coeff = 4.0 * eBe * ph.mu * dWVj * rcp_nr(r + 0.01 * h);
                 ax += coeff * (vxi - wj.y);
                 ay += coeff * (vyi - wj.z);
                 ix -= 2.0 * dWVj * tx;
@@ -766,15 +791,16 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     iy = group_sum<LPP>(iy);
     const double fpx = later ? fp_own.x : ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
     const double fpy = later ? fp_own.y : ay * Voli;
+    const double inv_m = rcp_nr(mi);
     if (active) {
-        const double acx = fpx / mi, acy = fpy / mi;
+        const double acx = fpx * inv_m, acy = fpy * inv_m;
         for (int m = first_wall; m < nn_all; ++m) {
             const int k = t.nl_idx[(size_t)m * t.nl_stride + tid] & (kWallBit - 1);
             const double2 pj = w.pos[k];
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-            const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
-            const double dWVj = spline_dW(ph.kc, r) * w.a[k].x;
+            const double dWVj = spline_dW_in(ph.kc, r) * w.a[k].x;
             const double face = -(acx * ex + acy * ey);
             const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
             const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
@@ -786,7 +812,6 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
     py = group_sum<LPP>(py);
     if (active && sub == 0) {
         const double fx = px * Voli, fy = py * Voli;
-        const double inv_m = 1.0 / mi;
         const double vxn = vxi + (fpx + fx) * inv_m * dt;
         const double vyn = vyi + (fpy + fy) * inv_m * dt;
         double sx = 0.0, sy = 0.0;
@@ -807,8 +832,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         t.f[i] = make_double2(fx, fy);
     }
     // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off));
+    d2 = wave_max(d2);
     __shared__ double s_d2[kBlock / 64];
     if ((threadIdx.x & 63) == 0) s_d2[threadIdx.x >> 6] = d2;
     __syncthreads();
@@ -1720,8 +1744,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         }
     }
     // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off));
+    d2 = wave_max(d2);
     __shared__ double s_d2[kBlock / 64];
     if ((threadIdx.x & 63) == 0) s_d2[threadIdx.x >> 6] = d2;
     __syncthreads();
@@ -1838,12 +1861,10 @@ __device__ __forceinline__ void continuity_tail(Clock *clk, int q, const Phys &p
         if (!lost) m = fmax(m, __longlong_as_double((long long)bits));
         __hip_atomic_store(slot, kVpartEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    m = wave_max(m);
+    d = wave_max(d);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m = fmax(m, __shfl_xor(m, off));
-        d = fmax(d, __shfl_xor(d, off));
-        lost |= __shfl_xor(lost, off);
-    }
+    for (int off = 32; off > 0; off >>= 1) lost |= __shfl_xor(lost, off);
     __shared__ double s_m[kBlock / 64], s_d[kBlock / 64];
     __shared__ int s_l[kBlock / 64];
     if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; s_l[threadIdx.x >> 6] = lost; }
@@ -1878,12 +1899,10 @@ __device__ __forceinline__ void slab_seal_tail(const Clock *clk, int q, const Fl
         if (!lost) m = fmax(m, __longlong_as_double((long long)bits));
         __hip_atomic_store(slot, kVpartEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    m = wave_max(m);
+    d = wave_max(d);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m = fmax(m, __shfl_xor(m, off));
-        d = fmax(d, __shfl_xor(d, off));
-        lost |= __shfl_xor(lost, off);
-    }
+    for (int off = 32; off > 0; off >>= 1) lost |= __shfl_xor(lost, off);
     __shared__ double s_m[kBlock / 64], s_d[kBlock / 64];
     __shared__ int s_l[kBlock / 64];
     if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; s_l[threadIdx.x >> 6] = lost; }
@@ -2017,10 +2036,10 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
                 vj = t.veln[k];
             }
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
-            const double r2 = dx * dx + dy * dy, inv_r = rsqrt(r2), r = r2 * inv_r;
+            const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
             const double u_jump = (vxi - vj.x) * ex + (vyi - vj.y) * ey;
-            rate += u_jump * spline_dW(ph.kc, r) * Volj;
+            rate += u_jump * spline_dW_sel(ph.kc, r) * Volj;
         }
     }
     rate = group_sum<LPP>(rate);
@@ -2053,8 +2072,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
             atomicAdd(&t.count[c], 1);
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v2 = fmax(v2, __shfl_xor(v2, off));
+    v2 = wave_max(v2);
     __shared__ double s_max[kBlock / 64];
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v2;
     __syncthreads();
