@@ -67,6 +67,7 @@ __device__ __forceinline__ bool owns(const Grid &g, double x, int cell)
 struct Phys {
     KernelConst kc;
     double rho0, inv_sigma0, mu, p0, c_f, g, tc, nu, DL, DH, w0;
+    double dt_viscous, dt_body;  // the two step limits that do not depend on the state (next_dt): 0.125 h^2 / nu, 0.25 sqrt(h / |g|)
 };
 
 // Device-side clock: replaces the host variables state.t / state.step / dt_step / remain of
@@ -235,6 +236,19 @@ __device__ __forceinline__ double wave_max(double v)
     v = fmax(v, __shfl_xor(v, 16));
     return fmax(v, __shfl_xor(v, 32));
 }
+// largest / smallest value of an int over the LPP lanes of a particle, in every lane (same stages as group_sum)
+template <int LPP, bool MAX>
+__device__ __forceinline__ int group_extreme(int v)
+{
+    auto pick = [](int a, int b) { return MAX ? max(a, b) : min(a, b); };
+    if (LPP >= 2) v = pick(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));
+    if (LPP >= 4) v = pick(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));
+    if (LPP >= 8) v = pick(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));
+    if (LPP >= 16) v = pick(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));
+#pragma unroll
+    for (int off = LPP / 2; off >= 16; off >>= 1) v = pick(v, __shfl_xor(v, off));
+    return v;
+}
 template <int LPP>
 __device__ __forceinline__ double group_sum(double v)
 {
@@ -274,8 +288,9 @@ __device__ __forceinline__ double next_dt(const Clock &c, const Phys &ph)
     const double remain = fmin(c.t_target - c.t, c.t_end - c.t);
     const double h = ph.kc.h;
     const double dt_acoustic = 0.25 * h / fmax(ph.c_f + c.vmax, 1e-12);
-    const double dt_viscous = 0.125 * h * h / fmax(ph.nu, 1e-12);
-    const double dt_body = 0.25 * sqrt(h / fmax(fabs(ph.g), 1e-12));
+    // (the clock's thread runs this between two steps, with the whole chip waiting: the viscous and the body-force limit -- two
+    //  divisions and a square root of constants -- come precomputed, make_phys)
+    const double dt_viscous = ph.dt_viscous, dt_body = ph.dt_body;
     if (c.n_in > 1) {
         // outer step by the advection / viscous / body-force scales, at most n_in acoustic steps long; dt is the inner step
         const double dt_adv = 0.25 * h / fmax(c.vmax, 1e-12);
@@ -480,7 +495,7 @@ __device__ __forceinline__ void density_body(const Clock *clk, int q, const Grid
     constexpr bool walk = MODE == 2;
     constexpr bool record = MODE == 1;  // also write the superset list
     if (walk) {
-        const int rows = LPP == 1 ? ns : __shfl(ns, gbase);  // lane 0 of the group owns the most rows
+        const int rows = group_extreme<LPP, true>(ns);  // (= lane 0's: it owns the most rows)
         if (active) {
             const double xi = pi.x, yi = pi.y;
             for (int m = 0; m < rows; ++m) {
@@ -1104,9 +1119,9 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     };
     const int ns = active ? list_rows(spacked) : 0;
     // group-uniform trip counts: lane 0 of the group owns the most rows, its last lane the fewest fluid rows
-    const int rows_all = LPP == 1 ? ns : __shfl(ns, gbase);
+    const int rows_all = group_extreme<LPP, true>(ns);
     const int my_fl = active ? list_fluid_rows(spacked) : 0;
-    const int rows_fl = LPP == 1 ? my_fl : __shfl(my_fl, gbase + LPP - 1);
+    const int rows_fl = group_extreme<LPP, false>(my_fl);
     const double xi = pi.x, yi = pi.y;
     double s_in = 0.0, s_ct = 0.0;
     // Three rows per turn.  A row is entry -> position -> test: the entries (16-bit index differences, two rows per word) run
@@ -1863,8 +1878,7 @@ __device__ __forceinline__ void continuity_tail(Clock *clk, int q, const Phys &p
     }
     m = wave_max(m);
     d = wave_max(d);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lost |= __shfl_xor(lost, off);
+    lost = __any(lost) ? 1 : 0;
     __shared__ double s_m[kBlock / 64], s_d[kBlock / 64];
     __shared__ int s_l[kBlock / 64];
     if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; s_l[threadIdx.x >> 6] = lost; }
@@ -1901,8 +1915,7 @@ __device__ __forceinline__ void slab_seal_tail(const Clock *clk, int q, const Fl
     }
     m = wave_max(m);
     d = wave_max(d);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lost |= __shfl_xor(lost, off);
+    lost = __any(lost) ? 1 : 0;
     __shared__ double s_m[kBlock / 64], s_d[kBlock / 64];
     __shared__ int s_l[kBlock / 64];
     if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; s_l[threadIdx.x >> 6] = lost; }
@@ -2129,7 +2142,7 @@ __global__ __launch_bounds__(kBlock) void k_continuity_density(Clock *clk, int q
 
 // the same with the large-channel forms of the two passes (mid-size channels: 4-8 lanes per particle, clock in the tail)
 template <int LPP>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8))) void k_continuity_density_w(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
+__global__ __launch_bounds__(kBlock) void k_continuity_density_w(Clock *clk, int q, Grid g, Phys ph, FluidSet s, FluidTmp t,
                                                                  Walls w, FluidSet s_next, FluidTmp t_next, int with_tail)
 {
     const int nb = ((int)gridDim.x - with_tail) / 2;  // (with_tail = 0: kernel timing, the clock must not advance)

@@ -919,6 +919,8 @@ Phys make_phys(const sphx_params *prm)
     ph.rho0 = prm->rho0; ph.inv_sigma0 = prm->inv_sigma0; ph.mu = prm->mu; ph.p0 = prm->p0; ph.c_f = prm->c_f;
     ph.g = prm->gravity_g; ph.tc = prm->transport_coeff; ph.nu = prm->mu / prm->rho0; ph.DL = prm->DL; ph.DH = prm->DH;
     ph.w0 = ph.kc.sigma;
+    ph.dt_viscous = 0.125 * prm->h * prm->h / std::max(ph.nu, 1e-12);
+    ph.dt_body = 0.25 * std::sqrt(prm->h / std::max(std::fabs(ph.g), 1e-12));
     return ph;
 }
 
