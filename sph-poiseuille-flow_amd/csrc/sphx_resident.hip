@@ -1130,7 +1130,11 @@ void choose_kernel_forms(sphx_ctx *c, bool lpp_given, double column_load, int n_
     // 100-130 k: equal; 194 k: 96.4 / 97.1; 259 k: 117.3 / 119.5; 360 k: 145.8 / 151.0 -- kept on at every size)
     // (round 3, layouts stored + slot-coded lists: 0.5 M 164 without / 175 us/step with -- it gives up the fused E|A launch --,
     //  0.83 M 260 / 260, 1.3 M 430 / 420; before that: 270 / 285 at 0.83 M, 440 / 457 at 1.3 M, hence 2 M then)
-    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= (dbg.tiles_be_from > 0 ? dbg.tiles_be_from : 1000000);
+    //  A slab has no fused launch to give up: in-process rings of 0.51 M / 0.76 M-particle slabs run 5 % / 9 % faster with the
+    //  tiles (C5 as 12 / 8 slabs: 2 970 -> 2 821, 2 546 -> 2 323 us/step), 0.25 M-particle slabs do not (276 / 279); a single
+    //  context of 0.76 M particles is a tie (239.5 / 239.8).
+    const int tiles_from = dbg.tiles_be_from > 0 ? dbg.tiles_be_from : (c->is_slab ? 500000 : 1000000);
+    c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= tiles_from;
     c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
     // every pass stages the same layout: the lists can name its slots (kSlotCodes) -- the index differences that remain need a
     // little more room than the plain ones
