@@ -1967,11 +1967,40 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const TileMap layout = (WALK && TILE > 0) ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     const double dt = clk->dt;
     const bool want_out = !WALK || step_outputs_wanted(clk, t);
+    const int cell_own = (g.own_by_cell && lead) ? s.cell[i] : 0;
     if (!clk->run[q]) return;
     const int n_now = clk->n;
     const bool active = i < n_now;
-    double rate = 0.0, v2 = 0.0;
+    double rate = 0.0;
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
+    // The workgroup's entry of the max |v|^2 reduction needs nothing but the particles' own records.  The compact kernels (small
+    // channels) publish it HERE, before the walk, so that the tail workgroup reduces and advances the clock while the walks are
+    // still running -- the clock update used to start when the last workgroup had finished (C1 14.55 -> 14.25, C2 17.55 -> 17.35
+    // us/step).  (Every workgroup has read what it needs of the clock by the time it publishes -- dt, the run flag, the
+    // population are read above -- and the tail cannot finish before all of them have published.)  The large-channel forms
+    // publish at the end as before: there the extra barrier in front of the walk costs more than the early clock gains (C3
+    // 44.5 -> 45.2 us/step with it).
+    auto publish_vmax = [&]() {
+        double v2 = 0.0;
+        if (active && sub == 0 && owns(g, xi, cell_own)) {
+            v2 = vxi * vxi + vyi * vyi;
+            if (v2 != v2) v2 = INFINITY;  // NaN poisons the max on purpose
+        }
+        v2 = wave_max(v2);
+        __shared__ double s_max[kBlock / 64];
+        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v2;
+        __syncthreads();
+        if (threadIdx.x == 0 && !next_half) {  // (an inner sub-step leaves the "ready" slots of the step's last pass E alone)
+            double m = s_max[0];
+            for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_max[k]);
+            if (tail)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(&t.vpart[blk]), (unsigned long long)__double_as_longlong(m),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                t.vpart[blk] = m;
+        }
+    };
+    if (!WALK) publish_vmax();
     if (WALK) {
         const int rows = active ? nn_all : 0, rows_fl = active ? list_fluid_rows(packed) : 0;
         TileMap tm{0, 0, 0, 0, 0, 0};
@@ -2071,10 +2100,6 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
             half_state(ph, rho, drho_new, dt, rhoh2, p2);
             t.a[i] = make_double4(a_own.x, p2, rhoh2, rho);
         }
-        if (owns(g, xi, g.own_by_cell ? s.cell[i] : 0)) {
-            v2 = vxi * vxi + vyi * vyi;
-            if (v2 != v2) v2 = INFINITY;  // NaN poisons the max on purpose
-        }
         // do_hist: 1 = this step re-bins (static schedule); 100 + K = dynamic context: the K-th step since the last
         // re-binning will re-bin whatever the drift says, so its histogram can be taken here (k_bin then skips)
         if (do_hist == 1 || (do_hist >= 100 && clk->pos_count >= do_hist - 101)) {
@@ -2085,19 +2110,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
             atomicAdd(&t.count[c], 1);
         }
     }
-    v2 = wave_max(v2);
-    __shared__ double s_max[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v2;
-    __syncthreads();
-    if (threadIdx.x == 0 && !next_half) {  // (an inner sub-step leaves the "ready" slots of the step's last pass E alone)
-        double m = s_max[0];
-        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_max[k]);
-        if (tail)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(&t.vpart[blk]), (unsigned long long)__double_as_longlong(m),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-            t.vpart[blk] = m;
-    }
+    if (WALK) publish_vmax();
 }
 
 // (waves_per_eu: the large-channel forms of passes E and A fit eight waves per SIMD by their vector registers (62-67) but took 106
