@@ -112,6 +112,47 @@ def test_call_pattern_does_not_change_the_bits(case, capi, kw):
             assert np.array_equal(outs[0][k], o[k]), k
 
 
+@pytest.mark.parametrize("lpp", [2, 4])
+def test_large_channel_kernels_hand_out_the_last_step_of_any_batch(case, capi, lpp):
+    """The large-channel kernels (few lanes per particle) write force, force_prior, rho and p in the LAST step of a batch only
+    (FluidTmp::lazy_out): whatever the call pattern -- one batch, single steps, back-to-back batches without a sync, a target time
+    instead of a step budget -- a download returns the outputs of the last executed step, bit for bit."""
+    prm, parts = case
+    n = 13
+    fields = ("pos", "vel", "rho", "p", "drho_dt", "force", "force_prior", "Vol", "B")
+    outs = []
+    with _ctx(capi, prm, parts, lanes_per_particle=lpp, rebuild_every=5) as a:
+        assert a.kernel_forms()["walk_kernels"]
+        st_a = a.advance(1e9, max_steps=n)
+        outs.append(a.download(fields=fields))
+    with _ctx(capi, prm, parts, lanes_per_particle=lpp, rebuild_every=5) as b:
+        for _ in range(n):
+            b.advance(1e9, max_steps=1)
+        outs.append(b.download(fields=fields))
+    with _ctx(capi, prm, parts, lanes_per_particle=lpp, rebuild_every=5) as c:
+        c.enqueue_steps(4)
+        c.enqueue_steps(6)
+        c.sync()
+        mid = c.download(fields=fields)                      # outputs of step 10 ...
+        c.enqueue_steps(3)
+        c.sync()
+        outs.append(c.download(fields=fields))
+    with _ctx(capi, prm, parts, lanes_per_particle=lpp, rebuild_every=5) as d:
+        d.advance(1e9, max_steps=10)
+        ten = d.download(fields=fields)                      # ... are those of a batch that ends there
+        st_d = d.advance(st_a["t"], max_steps=0)             # the rest by target time: the step that reaches it is the last
+        assert st_d["step"] == n
+        by_time = d.download(fields=fields)
+    for k in fields:
+        assert np.array_equal(mid[k], ten[k]), k
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][k], o[k]), k
+        # (the last dt of this one is clipped to the target: equal to rounding, not to the bit)
+        scale = float(np.max(np.abs(outs[0][k]))) or 1.0
+        assert_close(by_time[k], outs[0][k], rtol=1e-9, atol=1e-12 * scale, name="by time: " + k)
+    assert np.any(outs[0]["force"] != ten["force"])          # (and they did change in between)
+
+
 def test_cool_downs_follow_a_fixed_schedule(case, capi):
     """Every forced rebuild starts a cool-down (re-binning every step for 16, 32, ... steps) at a step index set by
     the device-side event alone; how the host chunks its calls does not matter -> still identical bits."""
