@@ -1574,8 +1574,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 {
     static_assert(!CODED || (TILE > 0 && TILE <= kSlotCodes), "slot-coded lists need a tile");
     constexpr int kSlots = TILE > 0 ? TILE : 1;
-    __shared__ double2 c_pos[kSlots], c_vel[kSlots];
-    __shared__ double4 c_a[kSlots], c_B[kSlots];
+    // (88 bytes per staged neighbour: of {Vol, p_half, rho_half, rho} the pass reads three)
+    __shared__ double2 c_pos[kSlots], c_vel[kSlots], c_vp[kSlots];
+    __shared__ double c_rh[kSlots];
+    __shared__ double4 c_B[kSlots];
     SPHX_PASS_INDEX();
     if (beyond_population<LPP>(clk, t, blk)) {  // (a slab's arrays have 15-20 % of slack: see beyond_population)
         if (threadIdx.x == 0 && clk->run[q]) t.dpart[blk] = 0.0;
@@ -1610,7 +1612,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
             const int k = tm.index(sl);
             c_pos[sl] = s.pos[k];
             c_vel[sl] = s.vel[k];
-            c_a[sl] = t.a[k];
+            const double4 ak = t.a[k];
+            c_vp[sl] = make_double2(ak.x, ak.y);
+            c_rh[sl] = ak.z;
             c_B[sl] = t.B[k];
         }
         __syncthreads();
@@ -1619,7 +1623,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     auto fetch_code = [&](int e) {  // (CODED)
         FluidNb n;
         if (e < n_staged) {  // (LDS-qualified reads: see k_kgc_w)
-            n.p = lds_double2(c_pos, e); n.v = lds_double2(c_vel, e); n.a = lds_double4(c_a, e); n.B = lds_double4(c_B, e);
+            const double2 vp = lds_double2(c_vp, e);
+            n.p = lds_double2(c_pos, e); n.v = lds_double2(c_vel, e); n.a = make_double4(vp.x, vp.y, lds_double(c_rh, e), 0.0); n.B = lds_double4(c_B, e);
             return n;
         }
         const int k = coded_index(layout, e, i, n_now);
@@ -1631,7 +1636,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         if (TILE > 0) {  // (early return, not if/else: see k_kgc_w)
             const int slot = tm.slot(k);
             if (slot >= 0) {
-                n.p = c_pos[slot]; n.v = c_vel[slot]; n.a = c_a[slot]; n.B = c_B[slot];
+                const double2 vp = c_vp[slot];
+                n.p = c_pos[slot]; n.v = c_vel[slot]; n.a = make_double4(vp.x, vp.y, c_rh[slot], 0.0); n.B = c_B[slot];
                 return n;
             }
         }

@@ -221,7 +221,7 @@ struct sphx_ctx {
 namespace {
 
 // A/B switches for measurements, all behind ONE environment variable read once per process:
-//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_lds_tiles,no_coded_lists,no_lazy_out,log
+//   SPHX_DEBUG_SWITCHES=no_tail_clock,no_fuse_ea,no_lds_tiles,no_coded_lists,no_lazy_out,forces_tile_320,log
 // (no_tail_clock: the clock update as a launch of its own on every step; no_fuse_ea: passes E and A in separate launches;
 //  no_lds_tiles: large-channel passes gather from global memory; no_coded_lists: index differences in every list, never tile
 //  slots; no_lazy_out: force, force_prior, rho, p written by every step (FluidTmp::lazy_out); log: forced re-binnings and timer
@@ -229,6 +229,7 @@ namespace {
 struct DebugSwitches {
     bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, no_coded_lists = false, no_lazy_out = false, log = false;
     int tail_limit = 0;  // > 0: largest pass (in workgroups) whose clock update rides in pass E's tail workgroup
+    int forces_tile = 0;    // 320: the old tile size of the slot-coded force pass
     int tiles_be_from = 0;  // > 0: passes B, E and A stage LDS tiles from this many resident particles (2 lanes per particle)
 };
 const DebugSwitches &debug_switches()
@@ -248,6 +249,7 @@ const DebugSwitches &debug_switches()
             if (has(("tail_limit_" + std::to_string(lim)).c_str())) d.tail_limit = lim;
         for (int from : {1, 250000, 500000, 750000, 1000000, 1500000, 3000000})
             if (has(("tiles_be_from_" + std::to_string(from)).c_str())) d.tiles_be_from = from;
+        if (has("forces_tile_320")) d.forces_tile = 320;
         return d;
     }();
     return sw;
@@ -399,7 +401,12 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
         }
         if (!only || only == 3) {
             if constexpr (LPP == 2) {
-                if (coded) launch(c, "k_forces", k_forces_w<LPP, 320, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+                // (the whole layout, four workgroups per CU: with 320 slots, five per CU, a quarter of the neighbours came from
+                //  global memory in nearly every trip of every wave -- 6 M particles 516 -> 489 us, forces_tile_320 for the old size)
+                if (coded) {
+                    if (debug_switches().forces_tile == 320) launch(c, "k_forces", k_forces_w<LPP, 320, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+                    else launch(c, "k_forces", k_forces_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+                }
             }
             if (coded) {}
             else if (c->lds_tiles) launch(c, "k_forces", k_forces_w<LPP, (LPP <= 2 ? 320 : T)>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
