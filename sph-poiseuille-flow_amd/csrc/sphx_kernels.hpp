@@ -393,7 +393,8 @@ __device__ __forceinline__ int encode_delta(int k, int i, int n, bool periodic, 
 // position in the workgroup's tile layout (tile_ranges at capacity kSlotCodes: own column, left, right -- a pass with a
 // smaller tile stages a prefix of the same layout); any other value is the index difference + kCodeBias (neighbours the
 // layout does not reach: a workgroup running across a column end, ranges longer than the layout).
-constexpr int kSlotCodes = 448;
+constexpr int kSlotCodes = 480;
+constexpr int kForceSlots = 448;  // the force pass stages this many (88-byte records, four workgroups per CU)
 constexpr int kCodeBias = 33000;
 constexpr int kCodedDeltaMax = 32500;  // kSlotCodes <= kCodeBias - kCodedDeltaMax,  kCodeBias + kCodedDeltaMax <= 65535
 __device__ __forceinline__ int code_lo(int word) { return word & 0xffff; }
@@ -1047,7 +1048,7 @@ __device__ __forceinline__ double4 lds_double4(const double4 *tile, int slot)
 }
 
 // tile capacity in particles: the three-column neighbourhood of kBlock / LPP particles at ~9 particles per cell
-__host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : (lpp == 4 ? 320 : 448); }
+__host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : (lpp == 4 ? 320 : 480); }
 
 // pass A, walking the superset list (see density_body MODE 2).  The LPP lanes of a particle test one list row at a
 // time and pack the accepted entries with ballot + popcount, so a group's trip count is uniform: the rows in which all

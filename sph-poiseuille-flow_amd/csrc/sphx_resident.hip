@@ -405,7 +405,7 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
                 //  global memory in nearly every trip of every wave -- 6 M particles 516 -> 489 us, forces_tile_320 for the old size)
                 if (coded) {
                     if (debug_switches().forces_tile == 320) launch(c, "k_forces", k_forces_w<LPP, 320, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
-                    else launch(c, "k_forces", k_forces_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+                    else launch(c, "k_forces", k_forces_w<LPP, kForceSlots, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
                 }
             }
             if (coded) {}
