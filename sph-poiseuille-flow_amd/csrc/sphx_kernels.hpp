@@ -1570,7 +1570,7 @@ struct FluidNb {
 
 // (CODED: slot-coded list entries, see kSlotCodes -- this pass's tile holds the first TILE slots of the layout)
 template <int LPP, int TILE, bool CODED = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 400 ? 4 : 5))) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                      FluidTmp t, Walls w)
 {
     static_assert(!CODED || (TILE > 0 && TILE <= kSlotCodes), "slot-coded lists need a tile");
