@@ -1980,6 +1980,23 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const bool active = i < n_now;
     double rate = 0.0;
     const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
+    // do_hist: 1 = this step re-bins (static schedule); 100 + K = dynamic context: the K-th step since the last re-binning will
+    // re-bin whatever the drift says, so its histogram can be taken here (k_bin then skips)
+    const bool hist = do_hist == 1 || (do_hist >= 100 && clk->pos_count >= do_hist - 101);
+    // Tiled form: the cell histogram goes through LDS.  A particle's new cell lies within a cell or two of the workgroup's old
+    // ones, so the workgroup counts into a window of kHistCols x kHistRows cells around its first particle's cell with LDS
+    // atomics and adds the window to the global histogram once -- 6 M global atomics, ~60 per cell and step, were 135 us of the
+    // pass on every step that takes the histogram (6 M particles).  Anything outside the window is counted globally as before.
+    constexpr bool kHistWindow = WALK && TILE > 0;
+    constexpr int kHistCols = 3, kHistRows = 48, kHistLead = 4;
+    __shared__ int h_win[kHistWindow ? kHistCols * kHistRows : 1];
+    int h_cx0 = 0, h_r0 = 0;
+    if (kHistWindow && hist) {
+        const int c_first = s.cell[min(blk * (kBlock / LPP), max(n_now - 1, 0))];
+        h_cx0 = c_first / g.ncy - 1;
+        h_r0 = c_first % g.ncy - kHistLead;
+        if (threadIdx.x < kHistCols * kHistRows) h_win[threadIdx.x] = 0;  // (the barrier behind the tile staging covers this)
+    }
     // The workgroup's entry of the max |v|^2 reduction needs nothing but the particles' own records.  The compact kernels (small
     // channels) publish it HERE, before the walk, so that the tail workgroup reduces and advances the clock while the walks are
     // still running -- the clock update used to start when the last workgroup had finished (C1 14.55 -> 14.25, C2 17.55 -> 17.35
@@ -2107,17 +2124,34 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
             half_state(ph, rho, drho_new, dt, rhoh2, p2);
             t.a[i] = make_double4(a_own.x, p2, rhoh2, rho);
         }
-        // do_hist: 1 = this step re-bins (static schedule); 100 + K = dynamic context: the K-th step since the last
-        // re-binning will re-bin whatever the drift says, so its histogram can be taken here (k_bin then skips)
-        if (do_hist == 1 || (do_hist >= 100 && clk->pos_count >= do_hist - 101)) {
+        if (hist) {
             int cx, cy;
             cell_of(g, pn.x, pn.y, cx, cy);
             const int c = cx * g.ncy + cy;
             t.cellid[i] = c;
-            atomicAdd(&t.count[c], 1);
+            bool counted = false;
+            if (kHistWindow) {
+                int dcol = cx - h_cx0;
+                if (g.periodic) dcol = dcol < 0 ? dcol + g.ncx : (dcol >= g.ncx ? dcol - g.ncx : dcol);
+                const int drow = cy - h_r0;
+                if ((unsigned)dcol < (unsigned)kHistCols && (unsigned)drow < (unsigned)kHistRows) {
+                    atomicAdd(&h_win[dcol * kHistRows + drow], 1);
+                    counted = true;
+                }
+            }
+            if (!counted) atomicAdd(&t.count[c], 1);
         }
     }
-    if (WALK) publish_vmax();
+    if (WALK) publish_vmax();  // (its barrier also closes the window histogram)
+    if (kHistWindow && hist && threadIdx.x < kHistCols * kHistRows) {
+        const int v = h_win[threadIdx.x];
+        if (v) {
+            int col = h_cx0 + (int)threadIdx.x / kHistRows;
+            if (g.periodic) col = col < 0 ? col + g.ncx : (col >= g.ncx ? col - g.ncx : col);
+            const int row = h_r0 + (int)threadIdx.x % kHistRows;
+            atomicAdd(&t.count[col * g.ncy + row], v);  // (v > 0: somebody's cell, so col and row are inside the grid)
+        }
+    }
 }
 
 // (waves_per_eu: the large-channel forms of passes E and A fit eight waves per SIMD by their vector registers (62-67) but took 106
