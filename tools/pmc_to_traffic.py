@@ -31,7 +31,8 @@ def main():
             name += {"0": "", "1": "_build", "2": "_walk"}[mode.group(1)]
         # the large-channel forms of the passes are launched under the names of the passes (bench.py's kernels_ms)
         name = name.replace("k_density_sweep_w", "k_density")
-        name = {"k_density_w": "k_density_walk", "k_kgc_w": "k_kgc", "k_forces_w": "k_forces"}.get(name, name)
+        name = {"k_density_w": "k_density_walk", "k_kgc_w": "k_kgc", "k_forces_w": "k_forces",
+                "k_continuity_density_w": "k_continuity_density"}.get(name, name)
         v = {}
         for item in kv:
             if "=" in item:
