@@ -181,6 +181,52 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
     return res, prm, parts, pos, vel
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` run bare (no launcher): start N ranks as CHILD processes, one per GPU, through
+    torch.distributed.run on 127.0.0.1, relay their output and exit with their code.  This parent makes no GPU call and
+    never replaces itself (no exec): it has not even imported torch."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    sys.stderr.write(f"bench.py: --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}\n")
+    sys.stderr.flush()
+    rc = subprocess.call(cmd, env=env, cwd=ROOT)
+    if rc != 0:
+        sys.stderr.write(f"bench.py: the {n}-rank run failed (exit {rc})\n")
+    raise SystemExit(rc)
+
+
+def check_launch(rank: int, world: int, args) -> None:
+    """--check-launch: every rank joins the gloo control plane, the ranks count themselves (all-reduce SUM of ones must
+    equal --gpus), rank 0 prints the launch fields of the JSON line.  Touches no GPU."""
+    n_seen = 1
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        n_seen = int(one.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if n_seen != args.gpus:
+        raise SystemExit(f"check-launch: {n_seen} rank(s) answered, --gpus {args.gpus}")
+    if rank == 0:
+        print(json.dumps({"metric": "particle-steps/s", "value": None, "unit": "particle-steps/s", "n_gpus": n_seen,
+                          "steps": args.steps, "warmup": args.warmup, "check_launch": True}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,16 +243,35 @@ def main():
     ap.add_argument("--no-aux", action="store_true", help="skip the C4/C5 side measurements of the default run")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--lattice", action="store_true", help="pristine lattice start instead of the developed state")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="bring the ranks up, agree on the world size over the control plane, print the line's launch "
+                         "fields (value null) and exit: no GPU call, no compute")
     args = ap.parse_args()
 
-    import numpy as np
+    # ---- launch decision: BEFORE anything touches the GPU (a process that has initialised HIP must never start
+    # or become another GPU program; the parent below only spawns children and relays their exit code) ----
+    world_env = os.environ.get("WORLD_SIZE")
+    under_launcher = world_env is not None and ("RANK" in os.environ or "TORCHELASTIC_RUN_ID" in os.environ)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not under_launcher:
+        if args.gpus > 1:
+            return launch_ranks(args.gpus, sys.argv[1:])
+        rank, world, local_rank = 0, 1, 0
+    else:
+        rank, world = int(os.environ.get("RANK", "0")), int(world_env)
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:  # includes world == 1 under a launcher with --gpus N: never measure something else silently
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); run\n"
+                             f"  python bench.py --gpus {args.gpus} ...   (bench.py starts its own ranks), or\n"
+                             f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                             f"--master-port P bench.py --gpus {args.gpus} ...\n")
+            raise SystemExit(2)
+    if args.check_launch:  # rendezvous only: no GPU call, no compute -- what the CPU test of the launch logic runs
+        return check_launch(rank, world, args)
+
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libsphx has no CPU fallback)")
     local_rank = local_rank % torch.cuda.device_count()

@@ -193,3 +193,49 @@ def test_rccl_calls_can_be_captured_into_a_graph():
     sys.path.insert(0, ROOT)
     pkg = importlib.import_module("sph-poiseuille-flow_amd")
     pkg.capi.check(pkg.capi.lib().sphx_comm_selftest_graph())
+
+
+def _bench(*argv, env=None, timeout=600):
+    e = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, cwd=ROOT, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def _json_line(stdout):
+    import json
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bare_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (children of a parent that makes no
+    GPU call) and report n_gpus = 2 -- not measure one GPU and say so quietly.  --check-launch stops after the rendezvous, so
+    this runs without a GPU."""
+    r = _bench("--gpus", "2", "--check-launch", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["check_launch"] is True
+    assert "starting 2 ranks" in r.stderr
+
+
+@pytest.mark.parametrize("world,gpus", [(1, 2), (1, 8), (2, 1)])
+def test_bench_rejects_a_world_size_that_is_not_gpus(world, gpus):
+    """Under a launcher (RANK / WORLD_SIZE set) a mismatch is an error with a non-zero exit -- including WORLD_SIZE = 1."""
+    r = _bench("--gpus", str(gpus), "--check-launch", env=dict(RANK="0", WORLD_SIZE=str(world), LOCAL_RANK="0",
+                                                               MASTER_ADDR="127.0.0.1", MASTER_PORT="29591"), timeout=120)
+    assert r.returncode == 2, (r.returncode, r.stdout, r.stderr)
+    assert f"--gpus {gpus}" in r.stderr and "{" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_bare_bench_two_ranks_share_the_gpu():
+    """The bare two-rank command for real: SPHX_DIST_BACKEND=gloo lets the ranks share the box's one GPU (messages staged
+    through host memory), everything else is the path `bench.py --gpus 2` takes on a two-GPU node."""
+    r = _bench("--gpus", "2", "--steps", "6", "--warmup", "2", "--no-aux", env=dict(SPHX_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "weak"
