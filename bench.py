@@ -36,16 +36,26 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_FLUID = {"k_density": 40, "k_kgc": 56, "k_forces": 112 + 192, "k_continuity": 104,
                    "k_clock_scan": 0, "k_scatter": 8, "k_reorder": 16}
 BYTES_PER_WALL = {"k_density": 24, "k_kgc": 24, "k_forces": 48, "k_continuity": 24}
-for _k in ("_build", "_walk", "_dyn"):  # pass A sweeping cells + recording the superset list / walking the superset list
-    BYTES_PER_FLUID["k_density" + _k] = BYTES_PER_FLUID["k_density"]
-    BYTES_PER_WALL["k_density" + _k] = BYTES_PER_WALL["k_density"]
-BYTES_PER_FLUID["k_continuity_clock"] = BYTES_PER_FLUID["k_continuity"]  # pass E carrying the clock update
-BYTES_PER_WALL["k_continuity_clock"] = BYTES_PER_WALL["k_continuity"]
-# small channels: pass E of a step and pass A of the next one in one launch
-BYTES_PER_FLUID["k_continuity_density"] = BYTES_PER_FLUID["k_continuity"] + BYTES_PER_FLUID["k_density"]
-BYTES_PER_WALL["k_continuity_density"] = BYTES_PER_WALL["k_continuity"] + BYTES_PER_WALL["k_density"]
+# Large-channel kernels (<= 8 lanes per particle) write the output-only fields of a step -- force, force_prior (pass CD: 32 B)
+# and rho, p (pass E: 16 B) -- in the LAST step of a batch only (FluidTmp::lazy_out): the bytes a replayed
+# launch of those passes is credited with are SURVEY 8d's minus the fields it does not write.
+LAZY_UNWRITTEN = {"k_forces": 32, "k_continuity": 16}
 STEP_BYTES_FLUID, STEP_BYTES_WALL = 528, 120
+_ALIAS = {"k_density_build": "k_density", "k_density_walk": "k_density", "k_density_dyn": "k_density",
+          "k_continuity_clock": "k_continuity"}
 
+
+def algorithmic_bytes(kernel, nf, nw, lazy):
+    """SURVEY 8d bytes of one launch of `kernel` on nf fluid / nw wall particles (lazy: see LAZY_UNWRITTEN)."""
+    if kernel == "k_continuity_density":  # pass E of a step and pass A of the next one in one launch
+        return algorithmic_bytes("k_continuity", nf, nw, lazy) + algorithmic_bytes("k_density", nf, nw, lazy)
+    k = _ALIAS.get(kernel, kernel)
+    per_fluid = BYTES_PER_FLUID.get(k, 0) - (LAZY_UNWRITTEN.get(k, 0) if lazy else 0)
+    return per_fluid * nf + BYTES_PER_WALL.get(k, 0) * nw
+
+
+def step_bytes(nf, nw, lazy):
+    return (STEP_BYTES_FLUID - (sum(LAZY_UNWRITTEN.values()) if lazy else 0)) * nf + STEP_BYTES_WALL * nw
 
 def parse_workload(s):
     if s in WORKLOADS:
@@ -113,7 +123,7 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
     ctx = capi.Context(prm, nf, nt, pos, vel, parts["drho_dt"], parts["mass"], parts["wall_vel"], t_end=1e9,
                        lanes_per_particle=lpp, steps_per_graph=spg, rebuild_every=rebuild_every,
                        skin_h=skin_h, dynamic_rebin=dynamic)
-    info, tuning = ctx.info(), ctx.tuning()
+    info, tuning, forms = ctx.info(), ctx.tuning(), ctx.kernel_forms()
     if warmup > 0:
         ctx.enqueue_steps(warmup)  # untimed: includes graph capture/instantiation
     st0 = ctx.sync()
@@ -144,16 +154,25 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
                 ms = ctx.time_kernel(dom, reps=max(20, min(400, int(0.05 / max(ms_eager * 1e-3, 1e-7)))))
             except capi.SphxError:
                 ms = ms_eager
-            alg = BYTES_PER_FLUID.get(dom, 0) * nf + BYTES_PER_WALL.get(dom, 0) * nw
+            lazy = bool(forms["walk_kernels"])  # (single contexts on the large-channel kernels: lazy_out = 1)
+            alg = algorithmic_bytes(dom, nf, nw, lazy)
             achieved = alg / (ms * 1e-3) / 1e9
+            traffic = pmc_traffic(name, dom)
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(name, dom),
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        # what the launch really moved through HBM, as a fraction of the peak (None without a PMC record)
+                        hbm_frac=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                        traffic_over_algorithmic=(traffic / alg) if traffic and alg else None,
                         traffic_source="profiles/pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch from separate "
                                        "rocprofv3 --pmc passes of this kernel on this workload, committed -- not "
                                        "collected in this run (counters need the profiler)",
                         launch_ms=ms, launch_ms_eager=ms_eager,
-                        algorithmic_bytes=alg,
-                        step_achieved=(STEP_BYTES_FLUID * nf + STEP_BYTES_WALL * nw) * steps / seconds / 1e9)
+                        algorithmic_bytes=alg, lazy_outputs=lazy,
+                        algorithmic_bytes_note="SURVEY 8d bytes per launch" + (
+                            " minus the output-only fields a non-final step does not write (force, force_prior: 32 B; rho, p: 16 B "
+                            "per fluid particle)" if lazy else ""),
+                        step_achieved=step_bytes(nf, nw, lazy) * steps / seconds / 1e9,
+                        step_achieved_survey8d=step_bytes(nf, nw, False) * steps / seconds / 1e9)
     sus = None
     if sustained:
         skip, n_sus = sustained
@@ -311,9 +330,9 @@ def main():
         # windows end before the synthetic start's jittered lattice breaks up (~500 steps in, a transient during which
         # nearly every step re-bins); sustained figures come from full physical runs
         # ... and, in the same context, the rate sustained once it has (`sustained`: 2 000 / 1 000 steps in)
-        for aux_name, aux_steps, aux_sus in (("C4", 300, (2000, 1000)), ("C5", 100, (1000, 300))):
+        for aux_name, aux_steps, aux_sus in (("C3", 2000, None), ("C4", 300, (2000, 1000)), ("C5", 100, (1000, 300))):
             try:
-                a = run_case(capi, cfg, geo, aux_name, dict(WORKLOADS[aux_name]), aux_steps, 40, 16, sustained=aux_sus)[0]
+                a = run_case(capi, cfg, geo, aux_name, dict(WORKLOADS[aux_name]), aux_steps, 40, 16 if aux_sus else 64, sustained=aux_sus)[0]
                 out["aux"][aux_name] = {k: a[k] for k in ("value", "ms_per_step", "roofline", "kernels_ms", "workload", "tuning", "sustained")}
                 out["aux"][aux_name]["window"] = (f"{aux_steps} steps right after a developed start; `sustained` = the same context "
                                                   "further in (disordered particles idle more lanes and the drift bound triggers "
@@ -326,7 +345,7 @@ def main():
             driver = importlib.import_module(PKG + ".driver")
             full = driver.run(cfg.params_from_values(dp=0.025, DL=3.0, end_time=20.0, output_interval=1.0))
             out["accuracy"] = {"config": "dp=0.025, DL=3, lattice at rest, t_end=20 s (BASELINE.md section 2: reference 39 496 steps, L2 0.84 %)",
-                               "L2": full.L2_error, "steps": full.steps, "wall_seconds": full.wall_seconds,
+                               "L2": full.L2_error, "L2_mean_profile_t16_20": full.L2_time_mean(last=5), "steps": full.steps, "wall_seconds": full.wall_seconds,
                                "particle_steps_per_s": full.particle_steps_per_s,
                                "wall_shear": [full.tau_bottom, full.tau_top], "wall_shear_target": full.tau_target}
         except Exception as e:

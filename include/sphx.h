@@ -201,7 +201,10 @@ int sphx_ctx_graph_stats(sphx_ctx *ctx, int64_t *slots_replayed, int64_t *slots_
 
 /* Copy state back in the caller's original row order.  Any pointer may be NULL.  rho,p,force,
  * force_prior,Vol,B are those of the last completed step (what integration_verlet / density_correction
- * returned in SPH_Poiseuille.m:254-266). */
+ * returned in SPH_Poiseuille.m:254-266).  Like sphx_ctx_sync, download and monitor first wait for everything
+ * enqueued and take the steps a batch of sphx_ctx_enqueue_steps still owes (a batch stops early when the cell
+ * grid goes stale): "last completed step" is the last step of everything asked for, and the state and the
+ * step outputs handed out belong to that same step. */
 int sphx_ctx_download(sphx_ctx *ctx, double *pos, double *vel, double *rho, double *p,
                       double *drho_dt, double *force, double *force_prior, double *Vol, double *B);
 

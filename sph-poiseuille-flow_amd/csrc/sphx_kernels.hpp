@@ -98,6 +98,10 @@ struct Clock {
     // pressure / continuity n_in times.  n_in = 1 is the reference's loop (SPH_Poiseuille.m:250-292), the parity path.
     int n_in;
     int pad2;
+    // pos_count as the step slot of parity q has to see it: written by the clock update of the slot BEFORE it (parity 1 - q,
+    // or k_prepare), never by the slot's own.  k_slab_pack3's workgroups take the re-binning decision each by itself while the
+    // last one out already advances the clock: a workgroup dispatched late must still read what the others read.
+    int pos_q[2];
 };
 
 // Everything a neighbour pass GATHERS per neighbour is stored as 16- or 32-byte records (position, velocity,
@@ -342,6 +346,8 @@ __global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_st
     const int go = loop_continues(c) ? 1 : 0;
     c.run[0] = q0 == 0 ? go : 0;  // constant indices: a dynamically indexed member forces the struct into scratch
     c.run[1] = q0 == 0 ? 0 : go;
+    c.pos_q[0] = c.pos_count;     // (the first slot of the batch reads its parity's copy; the other one is rewritten before use)
+    c.pos_q[1] = c.pos_count;
     c.seq += 1;
     *clk = c;
     if (!go && c.pub) *c.pub = c;
@@ -1822,6 +1828,8 @@ __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phy
         c.rebuild_now = rb ? (sched ? 2 : 1) : 0;     // 2: histogram done, k_bin skips
         c.fresh = c.rebuild_now;  // the next pass A starts from a fresh grid
         c.pos_count = rb ? 0 : c.pos_count + 1;
+        if (q == 0) c.pos_q[1] = c.pos_count;  // (for the NEXT slot; this slot's own copy stays as its workgroups read it)
+        else c.pos_q[0] = c.pos_count;
         c.drift = rb ? 0.0 : drift;
         if (by_drift) c.n_drift_rebuilds += 1;
         if (rb) c.n_rebins += 1;
@@ -2875,8 +2883,12 @@ __device__ __forceinline__ int wave_take_slot(int *counter, bool take)
 }
 
 // Global maxima known (vd_global = all-reduced {max |v|, max drift}): decide whether this step ends with a re-binning,
-// write message A, advance the clock.  Every workgroup takes the decision by itself from the OLD clock -- the clock is
-// only advanced by the last workgroup out, when nobody reads the old one any more.
+// write message A, advance the clock.  Every workgroup takes the decision by itself, from values the kernel's own epilogue
+// never changes: the run flag of this parity, the all-reduced drift, and Clock::pos_q[q] -- the copy of pos_count that the
+// PREVIOUS slot's clock update left for this one.  (On a frozen step only the first n_ticket workgroups draw a ticket, so
+// the last of them may advance the clock while a workgroup beyond n_ticket has not even been dispatched yet -- slabs of an
+// in-process ring share the chip; read from pos_count itself such a latecomer would see the NEW count, take the re-binning
+// branch on the step before a scheduled re-binning and pollute counters, histogram and ticket.)
 //   frozen step    : the new state of the send-list particles, in list order;
 //   re-binning step: every owned particle's new state goes to `keep` (it stays in this window) and, near a boundary,
 //                    to the neighbour -- as in k_slab_pack.
@@ -2894,7 +2906,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack3(Clock *clk, int q, Grid g
         return;
     }
     const double drift = vd_global[1];
-    const bool rb = !(drift <= half_skin) || clk->pos_count >= K - 1;  // = clock_step's decision (dyn_K = K)
+    const bool rb = !(drift <= half_skin) || clk->pos_q[q] >= K - 1;  // = clock_step's decision (dyn_K = K)
     const int stride = (int)gridDim.x * kBlock;
     int n_ticket = (int)gridDim.x;
     if (!rb) {

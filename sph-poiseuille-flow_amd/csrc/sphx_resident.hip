@@ -1409,11 +1409,12 @@ SPHX_EXPORT int sphx_ctx_graph_stats(sphx_ctx *c, int64_t *slots_replayed, int64
     SPHX_CATCH
 }
 
-SPHX_EXPORT int sphx_ctx_sync(sphx_ctx *c, sphx_status *status)
+// Wait for what is enqueued and take the steps a batch of sphx_ctx_enqueue_steps still owes: a batch stops early when the
+// drift bound is hit (static schedule) -- re-bin, then go on, in chunks (slots behind another stop would be empty launches).
+// Leaves the clock read.  Whoever hands out results calls this first: a batch that stopped before its armed last step has
+// not written the output-only fields of that step (FluidTmp::lazy_out), so force / rho / p would be those of an older batch.
+static void settle_owed(sphx_ctx *c)
 {
-    SPHX_TRY
-    require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
-    require(!c->is_slab, "SPHX:Ctx:slab", "use sphx_slab_sync on a slab context");
     read_clock(c);
     for (int guard = 0; guard < 1000000; ++guard) {
         const Clock &k = *c->h_clock;
@@ -1423,8 +1424,6 @@ SPHX_EXPORT int sphx_ctx_sync(sphx_ctx *c, sphx_status *status)
             forced_rebuild(c);
             c->chunk_slots = 64;
         }
-        // the batch stopped at a stale grid: take the steps still owed, in chunks (slots behind another stop
-        // would be empty launches)
         const int64_t n = std::min(owed, c->chunk_slots);
         arm_clock(c, c->prm.t_end, (long long)n, c->cur, (const double *)nullptr);
         enqueue_slots(c, n, false);
@@ -1432,6 +1431,14 @@ SPHX_EXPORT int sphx_ctx_sync(sphx_ctx *c, sphx_status *status)
         if (!c->h_clock->need_rebuild) c->chunk_slots = std::min<int64_t>(4096, 2 * c->chunk_slots);
     }
     c->pending_target = c->h_clock->step;
+}
+
+SPHX_EXPORT int sphx_ctx_sync(sphx_ctx *c, sphx_status *status)
+{
+    SPHX_TRY
+    require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
+    require(!c->is_slab, "SPHX:Ctx:slab", "use sphx_slab_sync on a slab context");
+    settle_owed(c);
     fill_status(c, status);
     throw_on_status(c);
     return SPHX_OK;
@@ -1444,7 +1451,7 @@ SPHX_EXPORT int sphx_ctx_download(sphx_ctx *c, double *pos, double *vel, double 
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     require(!c->is_slab, "SPHX:Ctx:slab", "use sphx_slab_snapshot on a slab context");
-    read_clock(c);
+    settle_owed(c);  // (state and step outputs of the SAME step: the last one of everything enqueued, see settle_owed)
     const bool need_outputs = rho || p || force || force_prior || Vol || B;
     if (need_outputs && !c->have_step_outputs)
         throw Error(SPHX_ERR_STATE, "SPHX:Ctx:download", "rho/p/force/Vol/B exist only after at least one step");
@@ -1504,7 +1511,7 @@ SPHX_EXPORT int sphx_ctx_monitor(sphx_ctx *c, double *tau_bottom, double *tau_to
     SPHX_TRY
     require(c != nullptr, "SPHX:Ctx:null", "ctx must not be NULL");
     require(!c->is_slab, "SPHX:Ctx:slab", "monitors are not available on a slab context");
-    read_clock(c);
+    settle_owed(c);
     if (c->h_clock->need_rebuild && c->h_clock->status == 0) forced_rebuild(c);  // the pair sweeps need valid bins
     hipStream_t s = c->stream;
     const FluidSet fs = c->view(c->cur, c->lay);

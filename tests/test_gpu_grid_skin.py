@@ -153,6 +153,33 @@ def test_large_channel_kernels_hand_out_the_last_step_of_any_batch(case, capi, l
     assert np.any(outs[0]["force"] != ten["force"])          # (and they did change in between)
 
 
+@pytest.mark.parametrize("lpp", [2, 4])
+def test_download_without_a_sync_takes_the_steps_a_stopped_batch_owes(case, capi, lpp):
+    """A batch of sphx_ctx_enqueue_steps on a skin far too thin stops early (drift bound, static schedule); its armed last step
+    -- the only one that writes force / force_prior / rho / p on the large-channel kernels -- has not run.  download and monitor
+    called straight away, without sphx_ctx_sync, must first take the owed steps like sync does: state AND outputs of step n."""
+    prm, parts = case
+    n = 23
+    with _ctx(capi, prm, parts, lanes_per_particle=lpp, rebuild_every=8, skin_h=0.03) as a:
+        assert a.kernel_forms()["walk_kernels"]
+        a.enqueue_steps(n)
+        st_a = a.sync()
+        assert st_a["step"] == n and a.grid_policy()["forced_rebuilds"] > 0  # (the batch did stop on the way)
+        ref = a.download(fields=FIELDS)
+        tau_ref = a.monitor(tau=True, pairs=True)
+    with _ctx(capi, prm, parts, lanes_per_particle=lpp, rebuild_every=8, skin_h=0.03) as b:
+        b.enqueue_steps(n)
+        got = b.download(fields=FIELDS)   # no sync
+        assert b.sync()["step"] == n
+    with _ctx(capi, prm, parts, lanes_per_particle=lpp, rebuild_every=8, skin_h=0.03) as c:
+        c.enqueue_steps(n)
+        tau_got = c.monitor(tau=True, pairs=True)   # no sync
+        assert c.sync()["step"] == n
+    for k in FIELDS:
+        assert np.array_equal(got[k], ref[k]), k
+    assert tau_got == tau_ref
+
+
 def test_cool_downs_follow_a_fixed_schedule(case, capi):
     """Every forced rebuild starts a cool-down (re-binning every step for 16, 32, ... steps) at a step index set by
     the device-side event alone; how the host chunks its calls does not matter -> still identical bits."""

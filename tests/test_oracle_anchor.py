@@ -143,22 +143,45 @@ def test_sort_keeps_physics(cfgmod, geom, oracle):
         assert_close(back, a[k], rtol=1e-9, atol_scale=1e-11, name=k)
 
 
+# Realisations recorded in this container (round 4; oracle, lattice at rest -> t = 20 s; L2 of the y-binned u_x profile at
+# t = 16, 17, 18, 19, 20 s | L2 of the profile AVERAGED over those five instants | steps):
+#   dp 0.05 (reference: 19 771 steps, 1.42 % at 20 s)
+#     serial          1.83 1.70 1.60 1.69 1.29 | 1.52 | REPLACED_BY_TEST_RUN
+#     8 OpenMP thr.   1.93 1.54 1.72 1.68 1.76 | 1.62 | 19 782
+#                     1.66 1.65 2.37 2.32 1.98 | 1.88 | 19 777
+#                     2.01 1.88 2.35 1.73 2.15 | 1.93 | 19 771
+#   dp 0.04, c_f 10, transport_coeff 0.10 (reference: 16 895 steps, 2.75 % at 20 s)
+#     serial          1.68 2.19 1.90 2.00 2.14 | 1.96 |
+#     8 OpenMP thr.   2.39 2.53 2.41 2.49 2.46 | 2.44 | 16 895
+#                     2.49 2.71 2.82 2.64 2.93 | 2.70 | 16 893
+# A single instant wanders by +-30 % within one realisation and between realisations (the flow is chaotic at round-off; with
+# more than one OpenMP thread the reference's atomic scatter makes every run a new realisation) -- round 3 asserted one such
+# instant of an 8-thread run inside 1.7 x the reference's and failed one CPU run in two.  Now: the SERIAL oracle, which is
+# deterministic (same bits every run in this image), the hard window on the five-instant mean profile (0.6 .. 1.5 x the
+# reference's figure: every realisation above lies inside 0.71 .. 1.36 x), a loose one on the last instant.
 @pytest.mark.parametrize("kw, ref_steps, ref_L2", [
     (dict(dp=0.05, DL=3.0), 19771, 0.0142),                                   # config.ini as shipped
     (dict(dp=0.04, DL=3.0, c_f=10.0, transport_coeff=0.10), 16895, 0.0275),    # README-table constants
 ])
 def test_full_runs_match_the_figures_recorded_from_the_reference(cfgmod, geom, oracle, profmod, kw, ref_steps, ref_L2):
     """steps to t = 20 s and L2(20 s) of the reference's own C code (compiled unmodified
-    at survey time).  The step count is the sum of the dt sequence, i.e. of the whole max|v| history; the flow
-    is chaotic at round-off, so the L2 of one realisation is compared within a window.  Two parameter sets:
-    different sound speed (dt rule, EOS stiffness) and shifting strength."""
+    at survey time).  The step count is the sum of the dt sequence, i.e. of the whole max|v| history.  Two parameter
+    sets: different sound speed (dt rule, EOS stiffness) and shifting strength.  ~35 s + ~45 s of one core."""
     prm = cfgmod.params_from_values(end_time=20.0, output_interval=20.0, **kw)
     parts = geom.init_particles(prm)
     nf = parts["n_fluid"]
-    oracle.set_num_threads(8)
-    st = oracle.run(prm, parts, t_end=20.0, output_interval=20.0, enable_sort=False, omp=True)
-    assert abs(st["stats"]["steps"] - ref_steps) <= 0.002 * ref_steps, (st["stats"]["steps"], ref_steps)
-    y, um, ue = profmod.final_profile(st["pos"][:nf], st["vel"][:nf, 0], prm)
-    L2 = profmod.l2_error(um, ue)
-    assert 0.5 * ref_L2 < L2 < 1.7 * ref_L2, (L2, ref_L2)
+    pos = vel = drho = None
+    t, steps, profiles, L2s = 0.0, 0, [], []
+    for t_out in (16.0, 17.0, 18.0, 19.0, 20.0):  # (every stop clips one dt: + 4 steps against the reference's single clip at t_end)
+        st = oracle.run(prm, parts, t_end=t_out, output_interval=t_out, enable_sort=False, omp=False,
+                        pos=pos, vel=vel, drho_dt=drho, t0=t, step0=steps)
+        pos, vel, drho, t = st["pos"], st["vel"], st["drho_dt"], t_out
+        steps += st["stats"]["steps"]
+        y, um, ue = profmod.final_profile(st["pos"][:nf], st["vel"][:nf, 0], prm)
+        profiles.append(um)
+        L2s.append(profmod.l2_error(um, ue))
+    assert abs(steps - ref_steps) <= 0.002 * ref_steps, (steps, ref_steps)
+    L2_mean = profmod.l2_error(np.nanmean(np.array(profiles), axis=0), ue)
+    assert 0.6 * ref_L2 < L2_mean < 1.5 * ref_L2, (L2_mean, L2s, ref_L2)       # the hard bound: the five-instant mean profile
+    assert 0.4 * ref_L2 < L2s[-1] < 2.0 * ref_L2, (L2s, ref_L2)                # one instant: loose
     assert abs(st["stats"]["tau_bottom"] - 0.4) < 0.04 and abs(st["stats"]["tau_top"] - 0.4) < 0.04

@@ -90,6 +90,10 @@ def test_slab_hip_two_ranks_half_million_particles():
     (4, 0.01, 6.0, 12, dict()),
     (2, 0.005, 12.0, 7, dict()),                             # 0.25 M particles per slab: multi-block scan, 2 lanes per particle
     (2, 0.004, 40.0, 7, dict()),                             # 1.25 M per slab: LDS tiles in every pass, slot-coded lists, stored tile layouts
+    # four slabs of 0.25 M particles, each on a stream of its own and competing for the chip: k_slab_pack3's grid is many times
+    # the workgroups a frozen step needs, so some are dispatched after the kernel's epilogue has advanced the clock -- they
+    # must still take the decision the others took (Clock::pos_q); 12 steps = two scheduled re-binnings and the steps before them
+    (4, 0.005, 24.0, 12, dict()),
     # the steps as ONE replayed hipGraph (sphx_slab_graph_prepare: ten steps per replay, kernels + copies + cross-stream
     # dependencies captured): prepared after the first call; 25 = two replays + five eager steps, and the last call finds
     # the other state parity -> eager again
