@@ -105,6 +105,13 @@ struct sphx_ctx {
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, sl_idx, sl_cnt, flags, tile;
     DevBuf<int> nl_pk, sl_pk, nl_pk2;  // large-channel kernels: fluid entries as 16-bit index differences (FluidTmp::nl_pk)
     DevBuf<int> tmap;                  // ... and every workgroup's tile layout (FluidTmp::tmap)
+    DevBuf<int> pid;                   // particle ids in perm order (k_scatter -> k_reorder)
+    // Dynamic contexts on the large-channel kernels: the two state parities and the temporaries of pos / vel / drho as ONE
+    // allocation each, [S0 | S1 | T] -- fpos_[0], fpos_[1], posn (...) are windows into it -- so that "the temporaries instead
+    // of the other parity" is an element offset the passes can add (FluidTmp::sched_off)
+    DevBuf<double2> pos3, vel3;
+    DevBuf<double> drho3;
+    bool sched_redirect = false;
     DevBuf<double2> wpos;
     DevBuf<double4> wa;
     DevBuf<int> wid, wstart, wrow_any;
@@ -228,6 +235,9 @@ namespace {
 //  problems on stderr)
 struct DebugSwitches {
     bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, no_coded_lists = false, no_lazy_out = false, log = false;
+    bool walk_superset = false;  // measurement (coded-list contexts): pass A sums sigma only, passes B, CD, E walk the superset list
+    bool no_sched_redirect = false;  // dynamic contexts: passes always write the other state parity, every re-binning copies back (round 3)
+    bool no_drift_top2 = false;  // the drift bound on the largest drift alone (d <= skin / 2), as up to round 3
     int tail_limit = 0;  // > 0: largest pass (in workgroups) whose clock update rides in pass E's tail workgroup
     int forces_tile = 0;    // 320: the old tile size of the slot-coded force pass
     int tiles_be_from = 0;  // > 0: passes B, E and A stage LDS tiles from this many resident particles (2 lanes per particle)
@@ -245,6 +255,9 @@ const DebugSwitches &debug_switches()
         d.no_coded_lists = has("no_coded_lists");
         d.no_lazy_out = has("no_lazy_out");
         d.log = has("log");
+        d.no_drift_top2 = has("no_drift_top2");
+        d.no_sched_redirect = has("no_sched_redirect");
+        d.walk_superset = has("walk_superset");
         for (int lim : {1024, 2048, 4096, 8192, 16384})
             if (has(("tail_limit_" + std::to_string(lim)).c_str())) d.tail_limit = lim;
         for (int from : {1, 250000, 500000, 750000, 1000000, 1500000, 3000000})
@@ -379,7 +392,8 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
                 bool done = false;
                 if constexpr (LPP == 2) {
                     if (c->coded_lists) {
-                        launch(c, "k_density_walk", k_density_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+                        if (debug_switches().walk_superset) launch(c, "k_density_walk", k_density_w<LPP, kSlotCodes, true, false>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+                        else launch(c, "k_density_walk", k_density_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
                         done = true;
                     }
                 }
@@ -391,9 +405,14 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
         // LDS tiles (tile_ranges): the force pass always; KGC and continuity where measured to pay (lds_tiles_be)
         bool coded = false;  // slot-coded lists (2 lanes per particle, every pass with a tile): the CODED forms of the same kernels
         if constexpr (LPP == 2) coded = c->coded_lists;
+        // measurement (walk_superset): passes B, CD and E on the superset list, with a kernel derivative that vanishes beyond 2h
+        const bool super = coded && debug_switches().walk_superset;
+        FluidTmp tsup = t;
+        tsup.nl_pk = t.sl_pk; tsup.nl_cnt = t.sl_cnt; tsup.nl_idx = t.sl_idx; tsup.nl_cap = t.sl_cap;
         if (!only || only == 2) {
             if constexpr (LPP == 2) {
-                if (coded) launch(c, "k_kgc", k_kgc_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
+                if (super) launch(c, "k_kgc", k_kgc_w<LPP, kSlotCodes, true, true>, gp, bp, clk, q, c->grid, c->phys, s, tsup, c->walls, c->fuse_ea ? 1 : 0);
+                else if (coded) launch(c, "k_kgc", k_kgc_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
             }
             if (coded) {}
             else if (c->lds_tiles_be) launch(c, "k_kgc", k_kgc_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
@@ -404,7 +423,8 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
                 // (the whole layout, four workgroups per CU: with 320 slots, five per CU, a quarter of the neighbours came from
                 //  global memory in nearly every trip of every wave -- 6 M particles 516 -> 489 us, forces_tile_320 for the old size)
                 if (coded) {
-                    if (debug_switches().forces_tile == 320) launch(c, "k_forces", k_forces_w<LPP, 320, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+                    if (super) launch(c, "k_forces", k_forces_w<LPP, kForceSlots, true, true>, gp, bp, clk, q, c->grid, c->phys, s, tsup, c->walls);
+                    else if (debug_switches().forces_tile == 320) launch(c, "k_forces", k_forces_w<LPP, 320, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
                     else launch(c, "k_forces", k_forces_w<LPP, kForceSlots, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
                 }
             }
@@ -413,12 +433,20 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             else launch(c, "k_forces", k_forces_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
         }
         if (!only || only == 4) {
+            // (launches without a tail workgroup get the instantiation without the tails' code: see k_continuity)
+            auto pass_e = [&](auto tile, auto is_coded) {
+                constexpr int TL = decltype(tile)::value;
+                constexpr bool CD = decltype(is_coded)::value;
+                const FluidTmp &te = super ? tsup : t;  // (pass E's kernel derivative vanishes beyond 2h as it is)
+                if (tail) launch(c, name_e, k_continuity<LPP, true, TL, CD, true>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, tail, 0);
+                else launch(c, name_e, k_continuity<LPP, true, TL, CD, false>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, 0, 0);
+            };
             if constexpr (LPP == 2) {
-                if (coded) launch(c, name_e, k_continuity<LPP, true, kSlotCodes, true>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
+                if (coded) pass_e(std::integral_constant<int, kSlotCodes>{}, std::true_type{});
             }
             if (coded) {}
-            else if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
-            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
+            else if (c->lds_tiles_be) pass_e(std::integral_constant<int, T>{}, std::false_type{});
+            else pass_e(std::integral_constant<int, 0>{}, std::false_type{});
         }
     }
 }
@@ -457,10 +485,12 @@ void launch_cell_scan(sphx_ctx *c, const Clock *clk, int q, int *start_next)
 void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderArgs &ra, const FluidSet &d, int max_blocks = 0)
 {
     const dim3 g1(max_blocks > 0 ? std::min(c->n_blocks_flat, max_blocks) : c->n_blocks_flat), bp(kBlock);
+    ReorderArgs rb = ra;
+    rb.pid = c->pid.get();
     launch(c, "k_scatter", k_scatter, g1, bp, clk, q, 0, (const int *)c->cellid.get(), c->count.get(), (const int *)d.start,
-           c->perm.get());
+           c->perm.get(), ra.id_src, c->pid.get());
     launch(c, "k_reorder", k_reorder, g1, bp, clk, q, 0, (const int *)c->cellid.get(), (const int *)d.start,
-           (const int *)c->perm.get(), ra);
+           (const int *)c->perm.get(), rb);
 }
 
 template <int LPP>
@@ -601,6 +631,10 @@ void launch_step_dyn(sphx_ctx *c, int q)
     const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
     FluidTmp t = c->tmp;
     t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+    if (c->sched_redirect) {  // on a scheduled re-binning the passes write the temporaries instead: (1 + q) * cap elements further on
+        t.sched_off = (1 + q) * c->cap;
+        t.sched_K = c->rebuild_every;
+    }
     launch_physics_any(c, q, s, t, 100 + c->rebuild_every, 0, 3);
     const double *vsrc = c->vpart.get(), *dsrc = c->dpart.get();
     int n_red = c->n_vpart;
@@ -615,15 +649,21 @@ void launch_step_dyn(sphx_ctx *c, int q)
     const int qf = q | kOnlyIfRebuild;
     const int kDynBlocks = 4096;  // grid-stride kernels: a launch that skips costs ~3 us instead of an empty 24k-block grid
     const dim3 g1(std::min(c->n_blocks_flat, kDynBlocks)), bp(kBlock);
-    // temporaries of the in-place re-binning: the tmp state arrays and the (otherwise unused) second layout
+    // Re-binning in place.  Temporaries: the tmp state arrays and the (otherwise unused) second layout.  The lean form
+    // (sched_redirect) writes what nobody reads during the re-ordering -- binning positions, cells, cell starts -- straight into
+    // the layout, gathers the state straight into the state arrays when the re-binning was a scheduled one (the passes wrote the
+    // temporaries, FluidTmp::sched_off), and copies back mass and id only (+ the state after a drift-triggered re-binning).
+    const bool lean = c->sched_redirect;
     const FluidSet d{c->posn.get(), c->veln.get(), c->drhon.get(), c->fmass_[1].get(), c->fid_[1].get(),
-                     c->fstart_[1].get(), c->fcell_[1].get(), c->fposb_[1].get()};
+                     lean ? o.start : c->fstart_[1].get(), lean ? o.cell : c->fcell_[1].get(), lean ? o.posb : c->fposb_[1].get()};
     launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, qf | kOnlyIfNoHistogram, c->grid, 0, (const double2 *)o.pos,
            c->cellid.get(), c->count.get());  // drift-triggered re-binnings only: pass E bins on the scheduled ones
     launch_cell_scan(c, clk, qf, d.start);
-    launch_scatter_reorder(c, clk, qf, reorder_args(o.pos, o.vel, o.drho, s.mass, s.id, d, c->tmp.src_of), d, kDynBlocks);
+    ReorderArgs ra = reorder_args(o.pos, o.vel, o.drho, s.mass, s.id, d, c->tmp.src_of);
+    ra.swap_on_scheduled = lean ? 1 : 0;
+    launch_scatter_reorder(c, clk, qf, ra, d, kDynBlocks);
     CopyBack cb{d.pos, d.vel, d.posb, o.pos, o.vel, o.posb, d.drho, d.mass, o.drho, o.mass, d.id, d.cell, d.start,
-                o.id, o.cell, o.start, c->grid.ncells + 1};
+                o.id, o.cell, o.start, c->grid.ncells + 1, lean ? 1 : 0};
     launch(c, "k_copyback", k_copyback, g1, bp, (const Clock *)clk, qf, cb);
 }
 
@@ -838,7 +878,7 @@ void forced_rebuild(sphx_ctx *c)
                        c->count.get());
     launch_cell_scan(c, nullptr, 0, d.start);
     hipLaunchKernelGGL(k_scatter, g1, bp, 0, st, (const Clock *)nullptr, 0, n, (const int *)c->cellid.get(), c->count.get(),
-                       (const int *)d.start, c->perm.get());
+                       (const int *)d.start, c->perm.get(), (const int *)nullptr, (int *)nullptr);
     // src_of: new slot -> slot of the layout the last step's outputs (rho, p, force, Vol, B) are stored in
     hipLaunchKernelGGL(k_reorder, g1, bp, 0, st, (const Clock *)nullptr, 0, n, (const int *)c->cellid.get(),
                        (const int *)d.start, (const int *)c->perm.get(),
@@ -913,7 +953,7 @@ void initial_sort(sphx_ctx *c, const Grid &g, int n, const double2 *pos, int *ce
     hipLaunchKernelGGL(k_bin, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, g, n, pos, cellid, count);
     hipLaunchKernelGGL(k_scan_only, dim3(1), dim3(kScanBlock), 0, s, (const Clock *)nullptr, 0, (const int *)count, start, g.ncells);
     hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
-                       (const int *)cellid, count, (const int *)start, perm);
+                       (const int *)cellid, count, (const int *)start, perm, (const int *)nullptr, (int *)nullptr);
     hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
                        (const int *)cellid, (const int *)start, (const int *)perm, ra);
     SPHX_HIP(hipGetLastError());
@@ -938,13 +978,25 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->cap = cap;
     c->n_blocks_particles = (int)div_up((size_t)cap * c->lpp, kBlock);
     c->n_blocks_flat = (int)div_up((size_t)cap, kBlock);
+    c->sched_redirect = c->dyn && c->walk_kernels && !debug_switches().no_sched_redirect;
+    if (c->sched_redirect) {
+        const size_t z = (size_t)cap;
+        c->pos3.alloc(3 * z); c->vel3.alloc(3 * z); c->drho3.alloc(3 * z);
+        for (int k = 0; k < 2; ++k) {
+            c->fpos_[k].view(c->pos3.get() + k * z, z); c->fvel_[k].view(c->vel3.get() + k * z, z);
+            c->fdrho_[k].view(c->drho3.get() + k * z, z);
+        }
+        c->posn.view(c->pos3.get() + 2 * z, z); c->veln.view(c->vel3.get() + 2 * z, z); c->drhon.view(c->drho3.get() + 2 * z, z);
+    }
     for (int k = 0; k < 2; ++k) {
-        c->fpos_[k].alloc(cap); c->fvel_[k].alloc(cap); c->fdrho_[k].alloc(cap); c->fmass_[k].alloc(cap);
+        if (!c->sched_redirect) { c->fpos_[k].alloc(cap); c->fvel_[k].alloc(cap); c->fdrho_[k].alloc(cap); }
+        c->fmass_[k].alloc(cap);
         c->fid_[k].alloc(cap); c->fstart_[k].alloc((size_t)g.ncells + 1); c->fcell_[k].alloc(cap);
         if (c->skin > 0.0) c->fposb_[k].alloc(cap);
     }
-    c->posn.alloc(cap); c->veln.alloc(cap); c->ffp.alloc(cap); c->ff.alloc(cap); c->fa.alloc(cap); c->fB.alloc(cap);
-    c->drhon.alloc(cap); c->rho_out.alloc(cap); c->p_out.alloc(cap); c->fvol.alloc(cap); c->fvol.zero(c->stream);
+    if (!c->sched_redirect) { c->posn.alloc(cap); c->veln.alloc(cap); c->drhon.alloc(cap); }
+    c->pid.alloc(cap);
+    c->ffp.alloc(cap); c->ff.alloc(cap); c->fa.alloc(cap); c->fB.alloc(cap); c->rho_out.alloc(cap); c->p_out.alloc(cap); c->fvol.alloc(cap); c->fvol.zero(c->stream);
     c->posn.zero(c->stream); c->veln.zero(c->stream); c->ffp.zero(c->stream); c->ff.zero(c->stream);
     c->fa.zero(c->stream); c->fB.zero(c->stream); c->drhon.zero(c->stream); c->rho_out.zero(c->stream); c->p_out.zero(c->stream);
     c->n_vpart = c->n_blocks_particles;
@@ -955,10 +1007,10 @@ void ctx_alloc(sphx_ctx *c, int cap)
     // (skinned slabs: the same hand-over feeds slab_seal_tail)
     const bool vpart_flags = c->tail_clock || (c->is_slab && c->rebuild_every > 1);
     SPHX_HIP(hipMemsetAsync(c->vpart.get(), vpart_flags ? 0xFF : 0, (size_t)c->n_vpart * sizeof(double), c->stream));
-    c->dpart.alloc(c->n_vpart);
+    c->dpart.alloc(2 * (size_t)c->n_vpart);  // (the two largest squared drifts per workgroup, see publish_drift_top2)
     c->dpart.zero(c->stream);
     c->n_vtiles = (!c->is_slab && c->n_vpart > 4 * kMaxTile) ? (int)div_up((size_t)c->n_vpart, kMaxTile) : 0;
-    if (c->n_vtiles) c->vtile.alloc(2 * (size_t)c->n_vtiles);
+    if (c->n_vtiles) c->vtile.alloc(3 * (size_t)c->n_vtiles);  // max |v|^2, then the drift pairs
     c->cellid.alloc(cap); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(cap); c->src_of.alloc(cap);
     c->count.zero(c->stream);
     const int nl_cap = nl_cap_for(c->lpp);
@@ -985,7 +1037,8 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, 0, nullptr};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, 0, nullptr,
+                      0, 0, debug_switches().no_drift_top2 ? 1 : 0};
     // (2 = never: a slab hands out its state only, sphx_slab_snapshot; the dual-rate loop, which reads force_prior in its
     //  inner sub-steps, runs on the compact kernels only)
     c->tmp.lazy_out = (c->walk_kernels && !debug_switches().no_lazy_out) ? (c->is_slab ? 2 : 1) : 0;

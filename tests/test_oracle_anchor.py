@@ -146,14 +146,15 @@ def test_sort_keeps_physics(cfgmod, geom, oracle):
 # Realisations recorded in this container (round 4; oracle, lattice at rest -> t = 20 s; L2 of the y-binned u_x profile at
 # t = 16, 17, 18, 19, 20 s | L2 of the profile AVERAGED over those five instants | steps):
 #   dp 0.05 (reference: 19 771 steps, 1.42 % at 20 s)
-#     serial          1.83 1.70 1.60 1.69 1.29 | 1.52 | REPLACED_BY_TEST_RUN
+#     serial          1.83 1.70 1.60 1.69 1.29 | 1.52 | 19 778 (stops at five output points: + 4 clipped steps)
 #     8 OpenMP thr.   1.93 1.54 1.72 1.68 1.76 | 1.62 | 19 782
 #                     1.66 1.65 2.37 2.32 1.98 | 1.88 | 19 777
 #                     2.01 1.88 2.35 1.73 2.15 | 1.93 | 19 771
 #   dp 0.04, c_f 10, transport_coeff 0.10 (reference: 16 895 steps, 2.75 % at 20 s)
-#     serial          1.68 2.19 1.90 2.00 2.14 | 1.96 |
+#     serial          1.68 2.19 1.90 2.00 2.14 | 1.96 | 16 897
 #     8 OpenMP thr.   2.39 2.53 2.41 2.49 2.46 | 2.44 | 16 895
 #                     2.49 2.71 2.82 2.64 2.93 | 2.70 | 16 893
+#                     3.11 3.08 3.07 3.12 2.94 | 3.05 | 16 896
 # A single instant wanders by +-30 % within one realisation and between realisations (the flow is chaotic at round-off; with
 # more than one OpenMP thread the reference's atomic scatter makes every run a new realisation) -- round 3 asserted one such
 # instant of an 8-thread run inside 1.7 x the reference's and failed one CPU run in two.  Now: the SERIAL oracle, which is
