@@ -96,7 +96,9 @@ struct Clock {
     // Opt-in dual-rate loop (sphx_params::dual_rate, the outer / inner stepping the reference's README describes): a step
     // slot is one OUTER step of n_in inner sub-steps of length dt -- density, KGC, viscous force and transport shift once,
     // pressure / continuity n_in times.  n_in = 1 is the reference's loop (SPH_Poiseuille.m:250-292), the parity path.
-    int n_in;
+    short n_in;
+    short sched_K;  // dynamic contexts: the re-binning interval K, for the passes that redirect their output on scheduled re-binnings
+                    // (kSchedRedirect); 0 otherwise
     // pos_count as the step slot of parity q has to see it: written by the clock update of the slot BEFORE it (parity 1 - q,
     // or k_prepare), never by the slot's own.  k_slab_pack3's workgroups take the re-binning decision each by itself while the
     // last one out already advances the clock: a workgroup dispatched late must still read what the others read.
@@ -157,15 +159,18 @@ struct FluidTmp {
                        // LAST step of a batch only, 2 = never, see step_outputs_wanted
     int *tmap;         // large-channel kernels: the tile layout of every workgroup (8 ints each, see tile_map_of), written by the
                        // cell sweep at each re-binning
-    // Dynamic contexts on the large-channel kernels: a SCHEDULED re-binning is known when the step starts (Clock::pos_count has
-    // reached sched_K - 1), so passes CD and E write the new state (posn, veln, drhon) sched_off elements further on -- into the
-    // temporaries -- and the re-ordering gathers from there straight into the state arrays: nothing to copy back (the three
-    // state arrays are [S0 | S1 | T] in one allocation each, see sphx_ctx::pos3).  0: off.
-    int sched_off;
-    int sched_K;
-    int drift_top1;    // 1 (SPHX_DEBUG_SWITCHES=no_drift_top2): the old single-value drift bound -- the second largest drift is
-                       // reported equal to the largest, which turns d1 + d2 <= skin into d1 <= skin / 2 (see top2_merge)
+    // (no new members: the force and continuity kernels sit exactly at their register budgets and twelve bytes more of kernel
+    //  arguments were enough to push values into scratch memory -- flags ride in has_slack, see kSlack / kDriftTop1 / kSchedRedirect)
 };
+// bits of FluidTmp::has_slack
+constexpr int kSlack = 1;          // the arrays hold markedly more slots than particles (slabs), see beyond_population
+constexpr int kDriftTop1 = 2;      // SPHX_DEBUG_SWITCHES=no_drift_top2: the old single-value drift bound -- the second largest drift is
+                                   // reported equal to the largest, which turns d1 + d2 <= skin into d1 <= skin / 2 (see top2_merge)
+// Dynamic contexts on the large-channel kernels: a SCHEDULED re-binning is known when the step starts (Clock::pos_count has
+// reached Clock::sched_K - 1), so passes CD and E of the step slot of parity q write the new state (posn, veln, drhon)
+// (1 + q) * cap elements further on -- into the temporaries -- and the re-ordering gathers from there straight into the state
+// arrays: nothing to copy back (the three state arrays are [S0 | S1 | T] in one allocation each, see sphx_ctx::pos3).
+constexpr int kSchedRedirect = 4;
 
 // "no value yet" in vpart when pass E carries the clock update in a tail workgroup (see continuity_tail)
 constexpr unsigned long long kVpartEmpty = ~0ull;
@@ -390,9 +395,9 @@ __device__ __forceinline__ bool step_outputs_wanted(const Clock *clk, const Flui
 
 // where passes CD and E of this step write / read the new state (see FluidTmp::sched_off); the clock still counts the steps
 // BEFORE this one while the passes run
-__device__ __forceinline__ int new_state_offset(const Clock *clk, const FluidTmp &t)
+__device__ __forceinline__ int new_state_offset(const Clock *clk, const FluidTmp &t, int q)
 {
-    return (t.sched_off != 0 && clk->pos_count >= t.sched_K - 1) ? t.sched_off : 0;
+    return ((t.has_slack & kSchedRedirect) && clk->pos_count >= clk->sched_K - 1) ? (1 + q) * t.cap : 0;
 }
 
 // Kernels of the re-binning chain take the slot parity with a flag: bit 1 set = "only when the clock says
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         t.f[i] = make_double2(fx, fy);
     }
     // the two largest drifts from the binning positions (bound how stale the cell grid may get, see top2_merge, Clock::drift)
-    publish_drift_top2(t.dpart, t.n_vpart, blk, d2, t.drift_top1 != 0);
+    publish_drift_top2(t.dpart, t.n_vpart, blk, d2, (t.has_slack & kDriftTop1) != 0);
 }
 
 // =================================================================================================
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
 template <int LPP>
 __device__ __forceinline__ bool beyond_population(const Clock *clk, const FluidTmp &t, int blk)
 {
-    return t.has_slack && blk * (kBlock / LPP) >= clk->n;
+    return (t.has_slack & kSlack) && blk * (kBlock / LPP) >= clk->n;
 }
 
 // A neighbour's x can be a period away from the particle's only if one of them was binned in the first or last cell
@@ -1665,9 +1670,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     const double2 vi = in_cap ? s.vel[i] : make_double2(0.0, 0.0);
     const double4 ai = in_cap ? t.a[i] : make_double4(1.0, 0.0, 0.0, 0.0);
     const double4 Bi = in_cap ? t.B[i] : make_double4(1.0, 0.0, 0.0, 1.0);
+    const double mi = in_cap ? s.mass[i] : 1.0;
     const int packed = t.nl_cnt[tid];
     const int w0 = t.nl_pk[tid], w1 = t.nl_pk[(size_t)t.nl_stride + tid];
     const bool tracked = s.posb != nullptr;
+    // (requested here although first used behind the walk: a load issued at the end of a workgroup's life is latency nobody
+    //  hides -- measured in round 4, mass and binning position read where they are used: 488 -> 660 us at 6 M particles)
+    const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
     const TileMap layout = TILE > 0 ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     const double dt = clk->dt;
     const bool want_out = step_outputs_wanted(clk, t);
@@ -1694,6 +1703,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
             c_B[sl] = t.B[k];
         }
         __syncthreads();
+    }
+    // The binning position and the mass are requested at the top (a load issued at the end of a workgroup's life is latency
+    // nobody hides) but first used behind the walk.  The mid-size forms (five workgroups per CU, 96 VGPRs, LDS to spare) park
+    // them in LDS for the duration of the walk: held in registers they tipped the allocation over -- the compiler spilled them
+    // to scratch memory, i.e. did the same thing through the memory hierarchy.
+    constexpr bool kPark = TILE > 0 && TILE <= 320 && LPP >= 2;  // (one lane per particle: 6 KB to park, a workgroup per CU less)
+    __shared__ double2 s_pb[kPark ? kBlock / LPP : 1];
+    __shared__ double s_mi[kPark ? kBlock / LPP : 1];
+    if (kPark && sub == 0) {
+        s_pb[threadIdx.x / LPP] = pb;
+        s_mi[threadIdx.x / LPP] = mi;
     }
     const int n_staged = tm.total();
     auto fetch_code = [&](int e) {  // (CODED)
@@ -1773,9 +1793,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
             const FluidNb n = fetch(k);
             fluid_pair(n, xi - n.p.x);
         });
-    // (the particle's mass is first needed behind the walks: requested here, its latency hides behind the wall rows and the
-    //  group sums -- two registers less through the fluid walk, see the binning position below)
-    const double mi = in_cap ? s.mass[i] : 1.0;
     // wall neighbours: viscous and transport now, pressure once force_prior is complete (p_wall needs it, :931-934)
     walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
         const double2 pj = w.pos[k];
@@ -1796,9 +1813,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     ay = group_sum<LPP>(ay) * ph.mu;
     ix = group_sum<LPP>(ix);
     iy = group_sum<LPP>(iy);
-    const double fpx = ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
+    const double mi_w = kPark ? s_mi[threadIdx.x / LPP] : mi;   // (every lane of the group needs it: a broadcast read)
+    const double2 pb_w = kPark ? s_pb[threadIdx.x / LPP] : pb;
+    const double fpx = ax * Voli + mi_w * ph.g;  // + gravity, SPH_Poiseuille.m:392
     const double fpy = ay * Voli;
-    const double inv_m = rcp_nr(mi);
+    const double inv_m = rcp_nr(mi_w);
     if (rows > rows_fl) {
         const double acx = fpx * inv_m, acy = fpy * inv_m;
         walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
@@ -1829,17 +1848,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
         xo += 0.5 * dt * vxn;
         yo += 0.5 * dt * vyn;
         if (tracked && (!g.own_by_cell || owns(g, 0.0, s.cell[i]))) {  // (a slab bounds the drift of what it owns)
-            // (the binning position is read HERE, not with the particle's own records at the top: four registers less to carry
-            //  through the walk in a kernel that sits exactly at its budget of 96 -- anything more went to scratch memory)
-            const double2 pb = s.posb[i];
-            const double ddx = min_image(g, xo - pb.x), ddy = yo - pb.y;
+            const double ddx = min_image(g, xo - pb_w.x), ddy = yo - pb_w.y;
             d2 = ddx * ddx + ddy * ddy;
             if (d2 != d2) d2 = INFINITY;
         }
         // periodic wrap (SPH_Poiseuille.m:570-577): a step moves a particle by a tiny fraction of DL, so x - floor(x/DL) DL
         // is x - DL, x + DL or x -- the same values without the division (a slab wraps when particles change owner)
         if (g.periodic) xo = xo >= ph.DL ? xo - ph.DL : (xo < 0.0 ? xo + ph.DL : xo);
-        const int out_at = new_state_offset(clk, t) + i;  // (the clock is still the one the step started with: it advances after pass E)
+        const int out_at = new_state_offset(clk, t, q) + i;  // (the clock is still the one the step started with: it advances after pass E)
         t.posn[out_at] = make_double2(xo, yo);
         t.veln[out_at] = make_double2(vxn, vyn);
         if (want_out) {
@@ -1848,7 +1864,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
         }
     }
     // the two largest drifts from the binning positions (bound how stale the cell grid may get, see top2_merge, Clock::drift)
-    publish_drift_top2(t.dpart, t.n_vpart, blk, d2, t.drift_top1 != 0);
+    publish_drift_top2(t.dpart, t.n_vpart, blk, d2, (t.has_slack & kDriftTop1) != 0);
 }
 
 // block-wide exclusive scan of one int per thread (NT threads); returns the block total
@@ -2070,7 +2086,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     // re-bin whatever the drift says, so its histogram can be taken here (k_bin then skips)
     const bool hist = do_hist == 1 || (do_hist >= 100 && clk->pos_count >= do_hist - 101);
     // ... and exactly on those steps of a dynamic context the passes find / leave the new state in the temporaries (FluidTmp::sched_off)
-    const int in_off = (WALK && hist) ? t.sched_off : 0;
+    const int in_off = (WALK && hist && (t.has_slack & kSchedRedirect)) ? (1 + q) * t.cap : 0;
     const double2 *const veln = t.veln + in_off;
     if (WALK) {
         if (in_cap) vi = veln[i];
@@ -2252,20 +2268,23 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
 // (waves_per_eu: the large-channel forms of passes E and A fit eight waves per SIMD by their vector registers (62-67) but took 106
 //  scalar registers -- seven waves; they are latency-bound, the eighth wave is worth 9 % of pass E at 6 M particles.  Asked for,
 //  the compiler finds a 78-SGPR allocation without spills.)
-// (TAILS = false: the instantiation for launches without a tail workgroup.  The tails hold a whole Clock in registers; in a
-//  kernel compiled for eight waves per SIMD -- 64 VGPRs, one of them taken by spilled scalars -- they, not the pass, decide
-//  whether anything goes to scratch memory, and a kernel with scratch pays for it in every wave.)
-template <int LPP, bool WALK, int TILE, bool CODED = false, bool TAILS = true>
+// (The large-channel forms are instantiated per tail.  The clock tail holds a whole Clock in registers; in a kernel compiled for
+//  eight waves per SIMD -- 64 VGPRs, one of them taken by spilled scalars -- it, not the pass, decides whether anything goes to
+//  scratch memory, and a kernel with scratch pays for it in every wave.)
+// TAILS: which tail the launch may carry -- 0 none, 1 the clock (continuity_tail), 2 a slab's local maxima (slab_seal_tail),
+// 3 either (decided by `tail` at run time: the compact kernels, which have registers to spare)
+template <int LPP, bool WALK, int TILE, bool CODED = false, int TAILS = 3>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WALK ? 8 : 1))) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
                                                        FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
     __shared__ double c_vol[kSlots];
-    if (!TAILS) tail = 0;
+    if (TAILS == 0) tail = 0;
+    else if (TAILS != 3) tail = tail ? TAILS : 0;
     const int nb = (int)gridDim.x - (tail ? 1 : 0);
-    if (TAILS && tail && (int)blockIdx.x == nb) {
-        if (tail == 2) slab_seal_tail(clk, q, t, nb);
+    if (TAILS != 0 && tail && (int)blockIdx.x == nb) {
+        if (TAILS == 2 || (TAILS == 3 && tail == 2)) slab_seal_tail(clk, q, t, nb);
         else continuity_tail(clk, q, ph, t, nb);
         return;
     }

@@ -438,8 +438,9 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
                 constexpr int TL = decltype(tile)::value;
                 constexpr bool CD = decltype(is_coded)::value;
                 const FluidTmp &te = super ? tsup : t;  // (pass E's kernel derivative vanishes beyond 2h as it is)
-                if (tail) launch(c, name_e, k_continuity<LPP, true, TL, CD, true>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, tail, 0);
-                else launch(c, name_e, k_continuity<LPP, true, TL, CD, false>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, 0, 0);
+                if (tail == 1) launch(c, name_e, k_continuity<LPP, true, TL, CD, 1>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, tail, 0);
+                else if (tail == 2) launch(c, name_e, k_continuity<LPP, true, TL, CD, 2>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, tail, 0);
+                else launch(c, name_e, k_continuity<LPP, true, TL, CD, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, 0, 0);
             };
             if constexpr (LPP == 2) {
                 if (coded) pass_e(std::integral_constant<int, kSlotCodes>{}, std::true_type{});
@@ -631,10 +632,8 @@ void launch_step_dyn(sphx_ctx *c, int q)
     const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
     FluidTmp t = c->tmp;
     t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
-    if (c->sched_redirect) {  // on a scheduled re-binning the passes write the temporaries instead: (1 + q) * cap elements further on
-        t.sched_off = (1 + q) * c->cap;
-        t.sched_K = c->rebuild_every;
-    }
+    // (sched_redirect: on a scheduled re-binning the passes write the temporaries instead, (1 + q) * cap elements further on --
+    //  kSchedRedirect in t.has_slack, Clock::sched_K)
     launch_physics_any(c, q, s, t, 100 + c->rebuild_every, 0, 3);
     const double *vsrc = c->vpart.get(), *dsrc = c->dpart.get();
     int n_red = c->n_vpart;
@@ -1037,8 +1036,9 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, 0, nullptr,
-                      0, 0, debug_switches().no_drift_top2 ? 1 : 0};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(),
+                      (c->is_slab ? kSlack : 0) | (debug_switches().no_drift_top2 ? kDriftTop1 : 0) | (c->sched_redirect ? kSchedRedirect : 0),
+                      nullptr, 0, nullptr};
     // (2 = never: a slab hands out its state only, sphx_slab_snapshot; the dual-rate loop, which reads force_prior in its
     //  inner sub-steps, runs on the compact kernels only)
     c->tmp.lazy_out = (c->walk_kernels && !debug_switches().no_lazy_out) ? (c->is_slab ? 2 : 1) : 0;
@@ -1135,7 +1135,8 @@ void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
     k.drift = 0.0; k.need_rebuild = 0;
     k.fresh = 1; k.rebuild_now = 0; k.pos_count = 0; k.n_drift_rebuilds = 0;
     k.seq = 0;
-    k.n_in = c->n_in;
+    k.n_in = (short)c->n_in;
+    k.sched_K = (short)(c->sched_redirect ? c->rebuild_every : 0);
     if (!c->h_pub) SPHX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pub), sizeof(Clock), hipHostMallocMapped));
     void *pub_dev = nullptr;
     SPHX_HIP(hipHostGetDevicePointer(&pub_dev, c->h_pub, 0));

@@ -1,7 +1,7 @@
 """Manual probe (not a test): one workload under several SPHX_DEBUG_SWITCHES settings, alternating, each in a fresh process.
     python tools/probes/probe_ab_switches.py C5 100 40 1000 300 3 "" no_drift_top2 no_sched_redirect ...
 args: workload, timed steps, warm-up, steps skipped before the sustained window (0: none), its length, repetitions, then the
-switch sets ("" = none).  Prints the window's and the sustained us/step, the drift-triggered re-binnings and (last repetition)
+switch sets ("" = none; "switches@tools/_exp/libsphx_r3.so" runs an older build of the library).  Prints the window's and the sustained us/step, the drift-triggered re-binnings and (last repetition)
 per-kernel times."""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,10 @@ for rep in range(reps):
     for v in variants:
         prof = 16 if rep == reps - 1 else 0
         src = code % (root, wl, steps, warm, prof, repr((skip, nsus)) if skip > 0 else "None")
-        env = dict(os.environ, SPHX_DEBUG_SWITCHES=v)
+        sw, _, lib = v.partition("@")  # "switches@path/to/libsphx.so": an older build (tools/build_baseline_lib.sh) in the same alternation
+        env = dict(os.environ, SPHX_DEBUG_SWITCHES=sw)
+        if lib:
+            env["SPHX_LIB"] = os.path.join(root, lib)
         p = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True)
         try:
             r = json.loads(p.stdout.strip().splitlines()[-1])
