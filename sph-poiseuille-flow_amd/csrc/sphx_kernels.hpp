@@ -286,28 +286,21 @@ __device__ __forceinline__ void wave_top2_pairs(double &m1, double &m2)
     }
 }
 // the workgroup's two largest squared drifts -> dpart (the end of both force kernels; d2: one value per lane, zero in lanes
-// that finish no particle).  Through LDS atomics on the order-preserving bits of the non-negative doubles, not through wave
-// reductions: the force kernels sit exactly at their register budget (96 VGPRs for five waves per SIMD), and two six-stage DPP
-// reductions on 64-bit values at their very end were enough to push values held across the walk into scratch memory.
+// that finish no particle).  (Wave reductions, then the four waves' pairs through LDS.  Measured the other way in round 4: all
+// lead lanes doing LDS atomics on ONE address serialise -- two rounds of them and three barriers were 3 us at the end of every
+// workgroup's life, where nothing hides them: the force pass 488 -> 640 us at 6 M particles, 51 -> 62 us at 0.5 M.)
 __device__ __forceinline__ void publish_drift_top2(double *dpart, int n_vpart, int blk, double d2, bool top1_only)
 {
-    __shared__ unsigned long long s_top[2];
-    __shared__ int s_ties;
-    if (threadIdx.x == 0) { s_top[0] = 0ull; s_top[1] = 0ull; s_ties = 0; }
-    __syncthreads();
-    const unsigned long long bits = nonneg_bits(d2);
-    if (bits) atomicMax(&s_top[0], bits);
-    __syncthreads();
-    const unsigned long long m1 = s_top[0];
-    if (bits) {
-        if (bits == m1) atomicAdd(&s_ties, 1);   // (two particles at the maximum: the second largest IS the maximum)
-        else atomicMax(&s_top[1], bits);
-    }
+    double m1, m2;
+    wave_top2(d2, m1, m2);
+    __shared__ double s_d1[kBlock / 64], s_d2[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_d1[threadIdx.x >> 6] = m1; s_d2[threadIdx.x >> 6] = m2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long m2 = (s_ties >= 2 || top1_only) ? m1 : s_top[1];
-        dpart[blk] = __longlong_as_double((long long)m1);
-        dpart[n_vpart + blk] = __longlong_as_double((long long)m2);
+        m1 = s_d1[0]; m2 = s_d2[0];
+        for (int k = 1; k < kBlock / 64; ++k) top2_merge(m1, m2, s_d1[k], s_d2[k]);
+        dpart[blk] = m1;
+        dpart[n_vpart + blk] = top1_only ? m1 : m2;
     }
 }
 
@@ -499,6 +492,33 @@ __device__ __forceinline__ int wrap_index(int k, int n) { return k < 0 ? k + n :
     const int i = tid / LPP, sub = tid % LPP;                              \
     const bool in_cap = i < t.cap
 #define SPHX_PASS_INDEX() SPHX_PASS_INDEX_AT((int)blockIdx.x, (int)gridDim.x)
+
+// Lane sorting (large-channel kernels).  A wavefront walks as many rows as its longest list, so the 32 particles of a wave
+// cost what the one with the most neighbours costs: in a disordered flow that is 8-13 % above the mean (tools/probes, round 4;
+// the gap between bench.py's window right after the synthetic start and its sustained figure).  Which PARTICLE of the
+// workgroup a lane pair works on is free -- every sum is per particle, everything across particles is a maximum or a count --
+// so the cell sweep, which knows the list lengths, sorts the workgroup's particles by length and leaves the assignment behind
+// the tile layouts (FluidTmp::tmap: 8 ints per workgroup, then one byte per particle slot); the walkers read their byte with
+// their first requests and take lanes 2k, 2k+1 -> particle pmap[k].  Waves then hold particles of similar length: 2-5 % above
+// the mean.  Results do not depend on the assignment, bit for bit.
+constexpr int kNoLaneSort = 8;  // bit of FluidTmp::has_slack (SPHX_DEBUG_SWITCHES=no_lane_sort): the sweep leaves the identity
+template <int LPP>
+__device__ __forceinline__ unsigned char *lane_map_of(const FluidTmp &t, int blk)
+{
+    return reinterpret_cast<unsigned char *>(t.tmap + 8 * (size_t)t.n_vpart) + (size_t)blk * (kBlock / LPP);
+}
+template <int LPP>
+__device__ __forceinline__ int lane_particle(const FluidTmp &t, int blk)  // the workgroup-local particle this lane works on
+{
+    const int local = (int)threadIdx.x / LPP;
+    return t.tmap != nullptr ? (int)lane_map_of<LPP>(t, blk)[local] : local;
+}
+#define SPHX_PASS_INDEX_W(bid, nblk)                                       \
+    const int blk = xcd_block((bid), (nblk));                              \
+    const int i = blk * (kBlock / LPP) + lane_particle<LPP>(t, blk);       \
+    const int sub = (int)threadIdx.x % LPP;                                \
+    const int tid = i * LPP + sub;                                         \
+    const bool in_cap = i < t.cap
 
 // ---------------------------------------------------------------------------------------------
 // pass A: candidate sweep -> neighbour list; number-density summation -> rho, Vol
@@ -1142,7 +1162,7 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
                                                   double2 *c_pos = nullptr)
 {
     static_assert(!CODED || TILE == kSlotCodes, "slot-coded lists: the walk stages the whole layout");
-    SPHX_PASS_INDEX_AT(bid, nblk);
+    SPHX_PASS_INDEX_W(bid, nblk);
     if (beyond_population<LPP>(clk, t, blk)) return;  // (nl_cnt of lanes beyond the population is never looked at)
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool lead = in_cap && sub == 0;
@@ -1519,12 +1539,45 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
                       : make_double4(mass_i / rho, 0.0, 0.0, rho);
         t.vol[i] = mass_i / rho;
     }
+    // the lane assignment of the walkers until the next sweep (see lane_particle): the workgroup's particles in the order of
+    // their list lengths -- a counting sort in LDS; equal lengths in arrival order, which changes nothing (results do not
+    // depend on the assignment)
+    if (t.tmap != nullptr) {
+        constexpr int kPer = kBlock / LPP;
+        const int local = (int)threadIdx.x / LPP;
+        unsigned char *pm = lane_map_of<LPP>(t, blk);
+        if (t.has_slack & kNoLaneSort) {
+            if (sub == 0) pm[local] = (unsigned char)local;
+        } else {
+            __shared__ int s_bins[64];
+            if (threadIdx.x < 64) s_bins[threadIdx.x] = 0;
+            __syncthreads();
+            const int key = active ? min(record ? scnt : cnt, 63) : 0;  // (the same in every lane of a group)
+            int arrival = 0;
+            if (sub == 0) arrival = atomicAdd(&s_bins[key], 1);
+            __syncthreads();
+            if (threadIdx.x < 64) {  // exclusive prefix over the 64 bins by the first wavefront
+                const int v = s_bins[threadIdx.x];
+                int inc = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(inc, off);
+                    if ((int)threadIdx.x >= off) inc += o;
+                }
+                s_bins[threadIdx.x] = inc - v;
+            }
+            __syncthreads();
+            if (sub == 0) pm[min(s_bins[key] + arrival, kPer - 1)] = (unsigned char)local;
+            __syncthreads();  // (the next tile of a grid-stride launch reuses s_bins)
+        }
+    }
 }
 
 // n_tiles: workgroup-sized tiles of the pass; the grid may be smaller (grid-stride over the tiles: the conditional launches
 // of a dynamic context, which are idle most of the time, see launch_physics)
+// (waves_per_eu: the sweep needs 79-81 vector registers, and 81 is five waves per SIMD where 80 is six)
 template <int LPP, int MODE, bool CODED = false>
-__global__ __launch_bounds__(kBlock) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                             FluidTmp t, Walls w, int cond_fresh, int n_tiles)
 {
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
@@ -1552,7 +1605,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots];
     __shared__ double c_vol[kSlots];
-    SPHX_PASS_INDEX();
+    SPHX_PASS_INDEX_W((int)blockIdx.x, (int)gridDim.x);
     if (beyond_population<LPP>(clk, t, blk)) return;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool closes = finish_half && in_cap && sub == 0;  // (see k_kgc)
@@ -1644,6 +1697,9 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     }
 }
 
+#ifndef SPHX_FORCES_WAVES
+#define SPHX_FORCES_WAVES 5  // waves per SIMD the mid-size forms of the force pass are compiled for (experiment builds: 4)
+#endif
 // pass CD (see k_forces); TILE > 0: neighbour records come from the LDS tile (tile_ranges)
 struct FluidNb {
     double2 p, v;
@@ -1652,7 +1708,7 @@ struct FluidNb {
 
 // (CODED: slot-coded list entries, see kSlotCodes -- this pass's tile holds the first TILE slots of the layout)
 template <int LPP, int TILE, bool CODED = false, bool SUPER = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 400 ? 4 : 5))) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 400 ? 4 : SPHX_FORCES_WAVES))) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                      FluidTmp t, Walls w)
 {
     static_assert(!CODED || (TILE > 0 && TILE <= kSlotCodes), "slot-coded lists need a tile");
@@ -1661,7 +1717,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     __shared__ double2 c_pos[kSlots], c_vel[kSlots], c_vp[kSlots];
     __shared__ double c_rh[kSlots];
     __shared__ double4 c_B[kSlots];
-    SPHX_PASS_INDEX();
+    SPHX_PASS_INDEX_W((int)blockIdx.x, (int)gridDim.x);
     if (beyond_population<LPP>(clk, t, blk)) {  // (a slab's arrays have 15-20 % of slack: see beyond_population)
         if (threadIdx.x == 0 && clk->run[q]) { t.dpart[blk] = 0.0; t.dpart[t.n_vpart + blk] = 0.0; }
         return;
@@ -2042,8 +2098,10 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
 {
     static_assert(!CODED || (WALK && TILE == kSlotCodes), "slot-coded lists: this pass stages the whole layout");
     const int blk = xcd_block(bid, nb);
-    const int tid = blk * kBlock + threadIdx.x;
-    const int i = tid / LPP, sub = tid % LPP;
+    // (the large-channel forms: lanes 2k, 2k+1 -> the particle the cell sweep assigned them, see lane_particle)
+    const int sub = (int)threadIdx.x % LPP;
+    const int i = blk * (kBlock / LPP) + (WALK ? lane_particle<LPP>(t, blk) : (int)threadIdx.x / LPP);
+    const int tid = i * LPP + sub;
     const bool in_cap = i < t.cap;
     if (WALK && beyond_population<LPP>(clk, t, blk)) {  // nothing here: only the workgroup's entry of the max |v|^2 reduction is owed
         if (threadIdx.x == 0 && clk->run[q] && !next_half) {
@@ -2619,6 +2677,13 @@ __global__ void k_rebinned(Clock *clk)
 {
     clk->drift = 0.0;
     clk->need_rebuild = 0;
+}
+
+// every workgroup's lane map = the identity (until the first cell sweep has sorted it, see lane_particle); per: kBlock / LPP
+__global__ __launch_bounds__(kBlock) void k_lane_map_identity(size_t n, int per, unsigned char *pm)
+{
+    const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k < n) pm[k] = (unsigned char)(k % (size_t)per);
 }
 
 __global__ __launch_bounds__(kBlock) void k_iota(int n, int *a, int base)

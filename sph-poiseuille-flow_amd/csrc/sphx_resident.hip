@@ -235,6 +235,7 @@ namespace {
 //  problems on stderr)
 struct DebugSwitches {
     bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, no_coded_lists = false, no_lazy_out = false, log = false;
+    bool no_lane_sort = false;   // the walkers' lanes take the workgroup's particles in index order (lane_particle stays the identity)
     bool walk_superset = false;  // measurement (coded-list contexts): pass A sums sigma only, passes B, CD, E walk the superset list
     bool no_sched_redirect = false;  // dynamic contexts: passes always write the other state parity, every re-binning copies back (round 3)
     bool no_drift_top2 = false;  // the drift bound on the largest drift alone (d <= skin / 2), as up to round 3
@@ -258,6 +259,7 @@ const DebugSwitches &debug_switches()
         d.no_drift_top2 = has("no_drift_top2");
         d.no_sched_redirect = has("no_sched_redirect");
         d.walk_superset = has("walk_superset");
+        d.no_lane_sort = has("no_lane_sort");
         for (int lim : {1024, 2048, 4096, 8192, 16384})
             if (has(("tail_limit_" + std::to_string(lim)).c_str())) d.tail_limit = lim;
         for (int from : {1, 250000, 500000, 750000, 1000000, 1500000, 3000000})
@@ -1037,14 +1039,19 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
                       c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(),
-                      (c->is_slab ? kSlack : 0) | (debug_switches().no_drift_top2 ? kDriftTop1 : 0) | (c->sched_redirect ? kSchedRedirect : 0),
+                      (c->is_slab ? kSlack : 0) | (debug_switches().no_drift_top2 ? kDriftTop1 : 0) | (c->sched_redirect ? kSchedRedirect : 0) |
+                          (debug_switches().no_lane_sort ? kNoLaneSort : 0),
                       nullptr, 0, nullptr};
     // (2 = never: a slab hands out its state only, sphx_slab_snapshot; the dual-rate loop, which reads force_prior in its
     //  inner sub-steps, runs on the compact kernels only)
     c->tmp.lazy_out = (c->walk_kernels && !debug_switches().no_lazy_out) ? (c->is_slab ? 2 : 1) : 0;
     if (c->walk_kernels) {  // (zeros = empty layouts until the first cell sweep has run)
-        c->tmap.alloc(8 * (size_t)c->n_blocks_particles); c->tmap.zero(c->stream);
+        // 8 ints of layout per workgroup, then one byte per particle slot: the walkers' lane assignment (lane_particle)
+        const size_t n_slots = (size_t)c->n_blocks_particles * (kBlock / c->lpp);
+        c->tmap.alloc(8 * (size_t)c->n_blocks_particles + (n_slots + 3) / 4); c->tmap.zero(c->stream);
         c->tmp.tmap = c->tmap.get();
+        hipLaunchKernelGGL(k_lane_map_identity, dim3(div_up(n_slots, kBlock)), dim3(kBlock), 0, c->stream, n_slots, kBlock / c->lpp,
+                           reinterpret_cast<unsigned char *>(c->tmap.get() + 8 * (size_t)c->n_blocks_particles));
     }
     // E|A fusion: small static-schedule channels on the compact kernels (the clock rides in the tail workgroup)
     c->fuse_ea = c->tail_clock && (c->lpp >= 16 || (c->walk_kernels && !c->lds_tiles_be && c->lpp >= 2)) && !debug_switches().no_fuse_ea;
