@@ -56,10 +56,10 @@ public:
     explicit DevBuf(size_t n) { alloc(n); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p_(o.p_), n_(o.n_), owned_(o.owned_) { o.p_ = nullptr; o.n_ = 0; o.owned_ = true; }
+    DevBuf(DevBuf &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept
     {
-        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; owned_ = o.owned_; o.p_ = nullptr; o.n_ = 0; o.owned_ = true; }
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
@@ -69,20 +69,11 @@ public:
         n_ = n;
         if (n) p_ = static_cast<T *>(pool_alloc(n * sizeof(T)));
     }
-    // a window of n elements into somebody else's allocation (not owned: the owner must outlive this view)
-    void view(T *p, size_t n)
-    {
-        release();
-        p_ = p;
-        n_ = n;
-        owned_ = false;
-    }
     void release()
     {
-        if (p_ && owned_) pool_free(p_, n_ * sizeof(T));
+        if (p_) pool_free(p_, n_ * sizeof(T));
         p_ = nullptr;
         n_ = 0;
-        owned_ = true;
     }
     void zero(hipStream_t s = nullptr)
     {
@@ -102,7 +93,6 @@ public:
 private:
     T *p_ = nullptr;
     size_t n_ = 0;
-    bool owned_ = true;
 };
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -96,14 +96,12 @@ struct Clock {
     // Opt-in dual-rate loop (sphx_params::dual_rate, the outer / inner stepping the reference's README describes): a step
     // slot is one OUTER step of n_in inner sub-steps of length dt -- density, KGC, viscous force and transport shift once,
     // pressure / continuity n_in times.  n_in = 1 is the reference's loop (SPH_Poiseuille.m:250-292), the parity path.
-    short n_in;
-    short sched_K;  // dynamic contexts: the re-binning interval K, for the passes that redirect their output on scheduled re-binnings
-                    // (kSchedRedirect); 0 otherwise
+    int n_in;
     // pos_count as the step slot of parity q has to see it: written by the clock update of the slot BEFORE it (parity 1 - q,
     // or k_prepare), never by the slot's own.  k_slab_pack3's workgroups take the re-binning decision each by itself while the
     // last one out already advances the clock: a workgroup dispatched late must still read what the others read.
     // (two shorts in the place of a padding word: a Clock lives in registers in the tail workgroups of pass E, whose kernels
-    //  sit exactly at their register budget)
+    //  sit exactly at their register budget -- the struct must not grow)
     short pos_q[2];
 };
 
@@ -159,18 +157,7 @@ struct FluidTmp {
                        // LAST step of a batch only, 2 = never, see step_outputs_wanted
     int *tmap;         // large-channel kernels: the tile layout of every workgroup (8 ints each, see tile_map_of), written by the
                        // cell sweep at each re-binning
-    // (no new members: the force and continuity kernels sit exactly at their register budgets and twelve bytes more of kernel
-    //  arguments were enough to push values into scratch memory -- flags ride in has_slack, see kSlack / kDriftTop1 / kSchedRedirect)
 };
-// bits of FluidTmp::has_slack
-constexpr int kSlack = 1;          // the arrays hold markedly more slots than particles (slabs), see beyond_population
-constexpr int kDriftTop1 = 2;      // SPHX_DEBUG_SWITCHES=no_drift_top2: the old single-value drift bound -- the second largest drift is
-                                   // reported equal to the largest, which turns d1 + d2 <= skin into d1 <= skin / 2 (see top2_merge)
-// Dynamic contexts on the large-channel kernels: a SCHEDULED re-binning is known when the step starts (Clock::pos_count has
-// reached Clock::sched_K - 1), so passes CD and E of the step slot of parity q write the new state (posn, veln, drhon)
-// (1 + q) * cap elements further on -- into the temporaries -- and the re-ordering gathers from there straight into the state
-// arrays: nothing to copy back (the three state arrays are [S0 | S1 | T] in one allocation each, see sphx_ctx::pos3).
-constexpr int kSchedRedirect = 4;
 
 // "no value yet" in vpart when pass E carries the clock update in a tail workgroup (see continuity_tail)
 constexpr unsigned long long kVpartEmpty = ~0ull;
@@ -254,56 +241,6 @@ __device__ __forceinline__ double wave_max(double v)
     v = fmax(v, __shfl_xor(v, 16));
     return fmax(v, __shfl_xor(v, 32));
 }
-// The drift bound on two values.  A pair of particles can be missed by the frozen lists only if the two of them TOGETHER have
-// moved further than the skin since the binning, so "no particle beyond skin / 2" is sufficient but not necessary: with d1 >=
-// d2 the two largest drifts (of distinct particles), d1 + d2 <= skin is the exact-for-every-pair form.  What outruns skin / 2
-// is nearly always ONE particle (a transport shift next to a void, 0.1-0.4 h in a step) while the second largest drift
-// stays at the few hundredths of h of ordinary motion: on millions of particles the single-value test re-binned 13 % of the
-// steps of a disordered flow for such outliers (C5, steps 1 000-1 400 after bench.py's start).  Pass CD therefore keeps the
-// two largest squared drifts per workgroup (FluidTmp::dpart: [0, n_vpart) the largest, [n_vpart, 2 n_vpart) the second).
-// top2_merge: fold the pair (x1 >= x2) of a DISJOINT set of particles into (m1 >= m2).
-__device__ __forceinline__ void top2_merge(double &m1, double &m2, double x1, double x2)
-{
-    const double lo = fmin(m1, x1);
-    m1 = fmax(m1, x1);
-    m2 = fmax(lo, fmax(m2, x2));
-}
-// the two largest of the wave's non-negative values (one per lane), in every lane
-__device__ __forceinline__ void wave_top2(double v, double &m1, double &m2)
-{
-    m1 = wave_max(v);
-    const bool top = v == m1;
-    const double rest = wave_max(top ? 0.0 : v);
-    m2 = __popcll(__ballot(top)) >= 2 ? m1 : rest;
-}
-// ... of the wave's PAIRS (each lane holds the top two of a disjoint set), in every lane
-__device__ __forceinline__ void wave_top2_pairs(double &m1, double &m2)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double x1 = __shfl_xor(m1, off), x2 = __shfl_xor(m2, off);
-        top2_merge(m1, m2, x1, x2);
-    }
-}
-// the workgroup's two largest squared drifts -> dpart (the end of both force kernels; d2: one value per lane, zero in lanes
-// that finish no particle).  (Wave reductions, then the four waves' pairs through LDS.  Measured the other way in round 4: all
-// lead lanes doing LDS atomics on ONE address serialise -- two rounds of them and three barriers were 3 us at the end of every
-// workgroup's life, where nothing hides them: the force pass 488 -> 640 us at 6 M particles, 51 -> 62 us at 0.5 M.)
-__device__ __forceinline__ void publish_drift_top2(double *dpart, int n_vpart, int blk, double d2, bool top1_only)
-{
-    double m1, m2;
-    wave_top2(d2, m1, m2);
-    __shared__ double s_d1[kBlock / 64], s_d2[kBlock / 64];
-    if ((threadIdx.x & 63) == 0) { s_d1[threadIdx.x >> 6] = m1; s_d2[threadIdx.x >> 6] = m2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m1 = s_d1[0]; m2 = s_d2[0];
-        for (int k = 1; k < kBlock / 64; ++k) top2_merge(m1, m2, s_d1[k], s_d2[k]);
-        dpart[blk] = m1;
-        dpart[n_vpart + blk] = top1_only ? m1 : m2;
-    }
-}
-
 // largest / smallest value of an int over the LPP lanes of a particle, in every lane (same stages as group_sum)
 template <int LPP, bool MAX>
 __device__ __forceinline__ int group_extreme(int v)
@@ -384,13 +321,6 @@ __device__ __forceinline__ bool step_outputs_wanted(const Clock *clk, const Flui
     if (!t.lazy_out) return true;
     if (t.lazy_out == 2) return false;  // (a slab: nobody can ask for them, sphx_slab_snapshot hands out the state only)
     return clk->steps_left == 1 || !(clk->t + clk->dt < clk->t_target - 1e-12);  // (the test of loop_continues, a step early)
-}
-
-// where passes CD and E of this step write / read the new state (see FluidTmp::sched_off); the clock still counts the steps
-// BEFORE this one while the passes run
-__device__ __forceinline__ int new_state_offset(const Clock *clk, const FluidTmp &t, int q)
-{
-    return ((t.has_slack & kSchedRedirect) && clk->pos_count >= clk->sched_K - 1) ? (1 + q) * t.cap : 0;
 }
 
 // Kernels of the re-binning chain take the slot parity with a flag: bit 1 set = "only when the clock says
@@ -492,33 +422,6 @@ __device__ __forceinline__ int wrap_index(int k, int n) { return k < 0 ? k + n :
     const int i = tid / LPP, sub = tid % LPP;                              \
     const bool in_cap = i < t.cap
 #define SPHX_PASS_INDEX() SPHX_PASS_INDEX_AT((int)blockIdx.x, (int)gridDim.x)
-
-// Lane sorting (large-channel kernels).  A wavefront walks as many rows as its longest list, so the 32 particles of a wave
-// cost what the one with the most neighbours costs: in a disordered flow that is 8-13 % above the mean (tools/probes, round 4;
-// the gap between bench.py's window right after the synthetic start and its sustained figure).  Which PARTICLE of the
-// workgroup a lane pair works on is free -- every sum is per particle, everything across particles is a maximum or a count --
-// so the cell sweep, which knows the list lengths, sorts the workgroup's particles by length and leaves the assignment behind
-// the tile layouts (FluidTmp::tmap: 8 ints per workgroup, then one byte per particle slot); the walkers read their byte with
-// their first requests and take lanes 2k, 2k+1 -> particle pmap[k].  Waves then hold particles of similar length: 2-5 % above
-// the mean.  Results do not depend on the assignment, bit for bit.
-constexpr int kNoLaneSort = 8;  // bit of FluidTmp::has_slack (SPHX_DEBUG_SWITCHES=no_lane_sort): the sweep leaves the identity
-template <int LPP>
-__device__ __forceinline__ unsigned char *lane_map_of(const FluidTmp &t, int blk)
-{
-    return reinterpret_cast<unsigned char *>(t.tmap + 8 * (size_t)t.n_vpart) + (size_t)blk * (kBlock / LPP);
-}
-template <int LPP>
-__device__ __forceinline__ int lane_particle(const FluidTmp &t, int blk)  // the workgroup-local particle this lane works on
-{
-    const int local = (int)threadIdx.x / LPP;
-    return t.tmap != nullptr ? (int)lane_map_of<LPP>(t, blk)[local] : local;
-}
-#define SPHX_PASS_INDEX_W(bid, nblk)                                       \
-    const int blk = xcd_block((bid), (nblk));                              \
-    const int i = blk * (kBlock / LPP) + lane_particle<LPP>(t, blk);       \
-    const int sub = (int)threadIdx.x % LPP;                                \
-    const int tid = i * LPP + sub;                                         \
-    const bool in_cap = i < t.cap
 
 // ---------------------------------------------------------------------------------------------
 // pass A: candidate sweep -> neighbour list; number-density summation -> rho, Vol
@@ -951,8 +854,16 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
         if (!later) t.fp[i] = make_double2(fpx, fpy);
         t.f[i] = make_double2(fx, fy);
     }
-    // the two largest drifts from the binning positions (bound how stale the cell grid may get, see top2_merge, Clock::drift)
-    publish_drift_top2(t.dpart, t.n_vpart, blk, d2, (t.has_slack & kDriftTop1) != 0);
+    // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
+    d2 = wave_max(d2);
+    __shared__ double s_d2[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_d2[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_d2[0];
+        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_d2[k]);
+        t.dpart[blk] = m;
+    }
 }
 
 // =================================================================================================
@@ -979,7 +890,7 @@ __global__ __launch_bounds__(kBlock) void k_forces(const Clock *clk, int q, Grid
 template <int LPP>
 __device__ __forceinline__ bool beyond_population(const Clock *clk, const FluidTmp &t, int blk)
 {
-    return (t.has_slack & kSlack) && blk * (kBlock / LPP) >= clk->n;
+    return t.has_slack && blk * (kBlock / LPP) >= clk->n;
 }
 
 // A neighbour's x can be a period away from the particle's only if one of them was binned in the first or last cell
@@ -1154,15 +1065,13 @@ __host__ __device__ constexpr int tile_slots(int lpp) { return lpp >= 8 ? 192 : 
 // only 16 bytes per candidate -- and, now that the pass runs at the texture addresser's limit, 6 % faster at 6 M: used
 // where KGC and continuity use theirs.)
 // (CODED: both lists hold slot-coded entries, see kSlotCodes -- the walk copies them as they stand)
-// (STORE = false -- the measurement behind SPHX_DEBUG_SWITCHES=walk_superset: the sigma-sum only, no list of the step is written;
-//  passes B, CD and E then walk the SUPERSET list themselves with a kernel derivative that vanishes beyond 2h)
-template <int LPP, int TILE = 0, bool CODED = false, bool STORE = true>
+template <int LPP, int TILE = 0, bool CODED = false>
 __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const Grid &g, const Phys &ph, const FluidSet &s,
                                                   const FluidTmp &t, const Walls &w, int bid, int nblk, bool half,
                                                   double2 *c_pos = nullptr)
 {
     static_assert(!CODED || TILE == kSlotCodes, "slot-coded lists: the walk stages the whole layout");
-    SPHX_PASS_INDEX_W(bid, nblk);
+    SPHX_PASS_INDEX_AT(bid, nblk);
     if (beyond_population<LPP>(clk, t, blk)) return;  // (nl_cnt of lanes beyond the population is never looked at)
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool lead = in_cap && sub == 0;
@@ -1197,7 +1106,6 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     //  popcounts were 9 of the ~55 vector instructions of a candidate in a pass that is ALU-bound; unsigned row arithmetic:
     //  m / LPP on a signed m costs a sign fix-up per use)
     auto push = [&](bool acc, int entry, bool wall) {
-        if constexpr (!STORE) return;
         int below, all;
         if constexpr (LPP == 2) {
             const int mine = acc ? 1 : 0, other = pair_partner(mine);
@@ -1314,15 +1222,13 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
                 else s_in += W;
             }
         }
-        if (STORE) cnt_fl += LPP == 1 ? ((acc && !wall) ? 1 : 0) : __popc(group_bits(acc && !wall));
+        cnt_fl += LPP == 1 ? ((acc && !wall) ? 1 : 0) : __popc(group_bits(acc && !wall));
         push(acc, e, wall);
     }
-    if (STORE) {
-        if (active && cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
-        cnt_fl = min(cnt_fl, cnt);
-        if (tid < t.nl_stride)
-            t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
-    }
+    if (active && cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
+    cnt_fl = min(cnt_fl, cnt);
+    if (tid < t.nl_stride)
+        t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {
@@ -1539,45 +1445,12 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
                       : make_double4(mass_i / rho, 0.0, 0.0, rho);
         t.vol[i] = mass_i / rho;
     }
-    // the lane assignment of the walkers until the next sweep (see lane_particle): the workgroup's particles in the order of
-    // their list lengths -- a counting sort in LDS; equal lengths in arrival order, which changes nothing (results do not
-    // depend on the assignment)
-    if (t.tmap != nullptr) {
-        constexpr int kPer = kBlock / LPP;
-        const int local = (int)threadIdx.x / LPP;
-        unsigned char *pm = lane_map_of<LPP>(t, blk);
-        if (t.has_slack & kNoLaneSort) {
-            if (sub == 0) pm[local] = (unsigned char)local;
-        } else {
-            __shared__ int s_bins[64];
-            if (threadIdx.x < 64) s_bins[threadIdx.x] = 0;
-            __syncthreads();
-            const int key = active ? min(record ? scnt : cnt, 63) : 0;  // (the same in every lane of a group)
-            int arrival = 0;
-            if (sub == 0) arrival = atomicAdd(&s_bins[key], 1);
-            __syncthreads();
-            if (threadIdx.x < 64) {  // exclusive prefix over the 64 bins by the first wavefront
-                const int v = s_bins[threadIdx.x];
-                int inc = v;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int o = __shfl_up(inc, off);
-                    if ((int)threadIdx.x >= off) inc += o;
-                }
-                s_bins[threadIdx.x] = inc - v;
-            }
-            __syncthreads();
-            if (sub == 0) pm[min(s_bins[key] + arrival, kPer - 1)] = (unsigned char)local;
-            __syncthreads();  // (the next tile of a grid-stride launch reuses s_bins)
-        }
-    }
 }
 
 // n_tiles: workgroup-sized tiles of the pass; the grid may be smaller (grid-stride over the tiles: the conditional launches
 // of a dynamic context, which are idle most of the time, see launch_physics)
-// (waves_per_eu: the sweep needs 79-81 vector registers, and 81 is five waves per SIMD where 80 is six)
 template <int LPP, int MODE, bool CODED = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+__global__ __launch_bounds__(kBlock) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                             FluidTmp t, Walls w, int cond_fresh, int n_tiles)
 {
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
@@ -1585,19 +1458,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6))) voi
         density_sweep_body_w<LPP, MODE, CODED>(clk, q, g, ph, s, t, w, b, n_tiles, true);
 }
 
-template <int LPP, int TILE = 0, bool CODED = false, bool STORE = true>
+template <int LPP, int TILE = 0, bool CODED = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((TILE > 0 || LPP <= 2) ? 8 : 1))) void k_density_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                       FluidTmp t, Walls w, int cond_fresh)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots];
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
-    density_walk_body<LPP, TILE, CODED, STORE>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true, c_pos);
+    density_walk_body<LPP, TILE, CODED>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true, c_pos);
 }
 
 // pass B (see k_kgc); CODED: slot-coded list entries (kSlotCodes)
-// (SUPER: the list is the superset list -- entries up to 2h + skin away --, see density_walk_body's STORE)
-template <int LPP, int TILE, bool CODED = false, bool SUPER = false>
+template <int LPP, int TILE, bool CODED = false>
 __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                   FluidTmp t, Walls w, int finish_half)
 {
@@ -1605,7 +1477,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots];
     __shared__ double c_vol[kSlots];
-    SPHX_PASS_INDEX_W((int)blockIdx.x, (int)gridDim.x);
+    SPHX_PASS_INDEX();
     if (beyond_population<LPP>(clk, t, blk)) return;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
     const bool closes = finish_half && in_cap && sub == 0;  // (see k_kgc)
@@ -1641,7 +1513,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     auto term = [&](double dx, double dy, double Volj) {
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
         const double ex = dx * inv_r, ey = dy * inv_r;
-        const double fxj = (SUPER ? spline_dW_sel(ph.kc, r) : spline_dW_in(ph.kc, r)) * Volj;
+        const double fxj = spline_dW_in(ph.kc, r) * Volj;
         a11 -= dx * (fxj * ex);
         a12 -= dx * (fxj * ey);
         a21 -= dy * (fxj * ex);
@@ -1697,9 +1569,6 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     }
 }
 
-#ifndef SPHX_FORCES_WAVES
-#define SPHX_FORCES_WAVES 5  // waves per SIMD the mid-size forms of the force pass are compiled for (experiment builds: 4)
-#endif
 // pass CD (see k_forces); TILE > 0: neighbour records come from the LDS tile (tile_ranges)
 struct FluidNb {
     double2 p, v;
@@ -1707,8 +1576,8 @@ struct FluidNb {
 };
 
 // (CODED: slot-coded list entries, see kSlotCodes -- this pass's tile holds the first TILE slots of the layout)
-template <int LPP, int TILE, bool CODED = false, bool SUPER = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 400 ? 4 : SPHX_FORCES_WAVES))) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+template <int LPP, int TILE, bool CODED = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 400 ? 4 : 5))) void k_forces_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                      FluidTmp t, Walls w)
 {
     static_assert(!CODED || (TILE > 0 && TILE <= kSlotCodes), "slot-coded lists need a tile");
@@ -1717,9 +1586,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     __shared__ double2 c_pos[kSlots], c_vel[kSlots], c_vp[kSlots];
     __shared__ double c_rh[kSlots];
     __shared__ double4 c_B[kSlots];
-    SPHX_PASS_INDEX_W((int)blockIdx.x, (int)gridDim.x);
+    SPHX_PASS_INDEX();
     if (beyond_population<LPP>(clk, t, blk)) {  // (a slab's arrays have 15-20 % of slack: see beyond_population)
-        if (threadIdx.x == 0 && clk->run[q]) { t.dpart[blk] = 0.0; t.dpart[t.n_vpart + blk] = 0.0; }
+        if (threadIdx.x == 0 && clk->run[q]) t.dpart[blk] = 0.0;
         return;
     }
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
@@ -1730,8 +1599,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     const int packed = t.nl_cnt[tid];
     const int w0 = t.nl_pk[tid], w1 = t.nl_pk[(size_t)t.nl_stride + tid];
     const bool tracked = s.posb != nullptr;
-    // (requested here although first used behind the walk: a load issued at the end of a workgroup's life is latency nobody
-    //  hides -- measured in round 4, mass and binning position read where they are used: 488 -> 660 us at 6 M particles)
     const double2 pb = (tracked && in_cap && sub == 0) ? s.posb[i] : make_double2(0.0, 0.0);
     const TileMap layout = TILE > 0 ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
     const double dt = clk->dt;
@@ -1759,17 +1626,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
             c_B[sl] = t.B[k];
         }
         __syncthreads();
-    }
-    // The binning position and the mass are requested at the top (a load issued at the end of a workgroup's life is latency
-    // nobody hides) but first used behind the walk.  The mid-size forms (five workgroups per CU, 96 VGPRs, LDS to spare) park
-    // them in LDS for the duration of the walk: held in registers they tipped the allocation over -- the compiler spilled them
-    // to scratch memory, i.e. did the same thing through the memory hierarchy.
-    constexpr bool kPark = TILE > 0 && TILE <= 320 && LPP >= 2;  // (one lane per particle: 6 KB to park, a workgroup per CU less)
-    __shared__ double2 s_pb[kPark ? kBlock / LPP : 1];
-    __shared__ double s_mi[kPark ? kBlock / LPP : 1];
-    if (kPark && sub == 0) {
-        s_pb[threadIdx.x / LPP] = pb;
-        s_mi[threadIdx.x / LPP] = mi;
     }
     const int n_staged = tm.total();
     auto fetch_code = [&](int e) {  // (CODED)
@@ -1808,7 +1664,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
         const double dy = yi - n.p.y;
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
         const double ex = dx * inv_r, ey = dy * inv_r;
-        const double dWVj = (SUPER ? spline_dW_sel(ph.kc, r) : spline_dW_in(ph.kc, r)) * n.a.x;
+        const double dWVj = spline_dW_in(ph.kc, r) * n.a.x;
         const double tx = (b11i + n.B.x) * ex + (b12i + n.B.y) * ey;
         const double ty = (b21i + n.B.z) * ex + (b22i + n.B.w) * ey;
         const double eBe = ex * tx + ey * ty;
@@ -1856,7 +1712,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
         const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
         const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
         const double ex = dx * inv_r, ey = dy * inv_r;
-        const double dWVj = (SUPER ? spline_dW_sel(ph.kc, r) : spline_dW_in(ph.kc, r)) * wj.x;
+        const double dWVj = spline_dW_in(ph.kc, r) * wj.x;
         const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
         const double eBe = ex * tx + ey * ty;
         const double coeff = 4.0 * eBe * dWVj * rcp_nr(r + soft);  // (mu: after the walk, see fluid_pair)
@@ -1869,11 +1725,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     ay = group_sum<LPP>(ay) * ph.mu;
     ix = group_sum<LPP>(ix);
     iy = group_sum<LPP>(iy);
-    const double mi_w = kPark ? s_mi[threadIdx.x / LPP] : mi;   // (every lane of the group needs it: a broadcast read)
-    const double2 pb_w = kPark ? s_pb[threadIdx.x / LPP] : pb;
-    const double fpx = ax * Voli + mi_w * ph.g;  // + gravity, SPH_Poiseuille.m:392
+    const double fpx = ax * Voli + mi * ph.g;  // + gravity, SPH_Poiseuille.m:392
     const double fpy = ay * Voli;
-    const double inv_m = rcp_nr(mi_w);
+    const double inv_m = rcp_nr(mi);
     if (rows > rows_fl) {
         const double acx = fpx * inv_m, acy = fpy * inv_m;
         walk_wall_rows(t, tid, rows_fl, rows, [&](int k) {
@@ -1881,7 +1735,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
             const double ex = dx * inv_r, ey = dy * inv_r;
-            const double dWVj = (SUPER ? spline_dW_sel(ph.kc, r) : spline_dW_in(ph.kc, r)) * w.a[k].x;
+            const double dWVj = spline_dW_in(ph.kc, r) * w.a[k].x;
             const double face = -(acx * ex + acy * ey);
             const double p_wall = p_i + rhoh_i * r * fmax(0.0, face);
             const double tx = b11i * ex + b12i * ey, ty = b21i * ex + b22i * ey;
@@ -1904,23 +1758,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
         xo += 0.5 * dt * vxn;
         yo += 0.5 * dt * vyn;
         if (tracked && (!g.own_by_cell || owns(g, 0.0, s.cell[i]))) {  // (a slab bounds the drift of what it owns)
-            const double ddx = min_image(g, xo - pb_w.x), ddy = yo - pb_w.y;
+            const double ddx = min_image(g, xo - pb.x), ddy = yo - pb.y;
             d2 = ddx * ddx + ddy * ddy;
             if (d2 != d2) d2 = INFINITY;
         }
         // periodic wrap (SPH_Poiseuille.m:570-577): a step moves a particle by a tiny fraction of DL, so x - floor(x/DL) DL
         // is x - DL, x + DL or x -- the same values without the division (a slab wraps when particles change owner)
         if (g.periodic) xo = xo >= ph.DL ? xo - ph.DL : (xo < 0.0 ? xo + ph.DL : xo);
-        const int out_at = new_state_offset(clk, t, q) + i;  // (the clock is still the one the step started with: it advances after pass E)
-        t.posn[out_at] = make_double2(xo, yo);
-        t.veln[out_at] = make_double2(vxn, vyn);
+        t.posn[i] = make_double2(xo, yo);
+        t.veln[i] = make_double2(vxn, vyn);
         if (want_out) {
             t.fp[i] = make_double2(fpx, fpy);
             t.f[i] = make_double2(fx, fy);
         }
     }
-    // the two largest drifts from the binning positions (bound how stale the cell grid may get, see top2_merge, Clock::drift)
-    publish_drift_top2(t.dpart, t.n_vpart, blk, d2, (t.has_slack & kDriftTop1) != 0);
+    // largest drift from the binning positions (bounds how stale the cell grid may get, see Clock::drift)
+    d2 = wave_max(d2);
+    __shared__ double s_d2[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_d2[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_d2[0];
+        for (int k = 1; k < kBlock / 64; ++k) m = fmax(m, s_d2[k]);
+        t.dpart[blk] = m;
+    }
 }
 
 // block-wide exclusive scan of one int per thread (NT threads); returns the block total
@@ -1957,14 +1818,12 @@ __device__ __forceinline__ int block_exclusive_scan_t(int v, int &total, int *s_
 // advance the device clock by the step that has just been computed (one thread)
 // drift: largest distance from the binning positions (< 0: not tracked); rebuilt: this step ends with a fresh grid.
 // dyn_K > 0: dynamic context -- decide here whether this step ends with a re-binning (K-th step, or drift bound hit)
-// drift2 >= 0: the second largest drift is known too -- the bound is drift + drift2 <= skin (see top2_merge), not drift <= skin / 2
 __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phys &ph, double vmax, int flags,
                                            int n_new, double drift = -1.0, int rebuilt = 1, double half_skin = 0.0,
-                                           int dyn_K = 0, double drift2 = -1.0)
+                                           int dyn_K = 0)
 {
-    const bool stale = drift2 >= 0.0 ? !(drift + drift2 <= 2.0 * half_skin) : !(drift <= half_skin);
     if (dyn_K > 0) {
-        const bool by_drift = stale;
+        const bool by_drift = !(drift <= half_skin);
         const bool sched = c.pos_count >= dyn_K - 1;  // pass E has taken the histogram already
         const bool rb = by_drift || sched;
         c.rebuild_now = rb ? (sched ? 2 : 1) : 0;     // 2: histogram done, k_bin skips
@@ -1977,9 +1836,9 @@ __device__ __forceinline__ void clock_step(Clock *clk, Clock c, int q, const Phy
         if (rb) c.n_rebins += 1;
     } else if (drift >= 0.0) {
         c.drift = rebuilt ? 0.0 : drift;
-        // every step sweeps the cells the particles were BINNED into; that finds all neighbours only while no two
-        // particles together have drifted more than the skin -> stop the loop, the host re-bins and resumes
-        if (!rebuilt && stale) c.need_rebuild = 1;
+        // every step sweeps the cells the particles were BINNED into; that finds all neighbours only while no
+        // particle has drifted more than half the skin -> stop the loop, the host re-bins and resumes
+        if (!(c.drift <= half_skin)) c.need_rebuild = 1;
     }
     c.vmax = vmax;
     c.t += c.n_in > 1 ? c.dt * c.n_in : c.dt;  // SPH_Poiseuille.m:267 (dual-rate: n_in sub-steps of dt were taken)
@@ -2018,9 +1877,6 @@ __device__ __forceinline__ void continuity_tail(Clock *clk, int q, const Phys &p
     Clock c0;
     int fl = 0;
     if (threadIdx.x == 0) { c0 = *clk; fl = *t.flags; }
-    // (the single-value drift bound here -- d <= skin / 2, the largest entry of every workgroup's pair: this tail serves the
-    //  small and mid-size channels, where a forced re-binning is rare and cheap, and it lives inside pass E's kernel, whose
-    //  register budget (eight waves per SIMD) the pair reduction would break: top2_merge is for the clock kernels)
     double m = 0.0, d = 0.0;
     int lost = 0;
     const bool track = t.half_skin >= 0.0;
@@ -2098,10 +1954,8 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
 {
     static_assert(!CODED || (WALK && TILE == kSlotCodes), "slot-coded lists: this pass stages the whole layout");
     const int blk = xcd_block(bid, nb);
-    // (the large-channel forms: lanes 2k, 2k+1 -> the particle the cell sweep assigned them, see lane_particle)
-    const int sub = (int)threadIdx.x % LPP;
-    const int i = blk * (kBlock / LPP) + (WALK ? lane_particle<LPP>(t, blk) : (int)threadIdx.x / LPP);
-    const int tid = i * LPP + sub;
+    const int tid = blk * kBlock + threadIdx.x;
+    const int i = tid / LPP, sub = tid % LPP;
     const bool in_cap = i < t.cap;
     if (WALK && beyond_population<LPP>(clk, t, blk)) {  // nothing here: only the workgroup's entry of the max |v|^2 reduction is owed
         if (threadIdx.x == 0 && clk->run[q] && !next_half) {
@@ -2111,9 +1965,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
         return;
     }
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
-    // (the large-channel forms may find the new state in the temporaries -- FluidTmp::sched_off -- and know where only once they
-    //  have the clock: they request it with their staging loads / first gathers, which wait for the clock anyway)
-    double2 vi = (!WALK && in_cap) ? t.veln[i] : make_double2(0.0, 0.0);
+    const double2 vi = in_cap ? t.veln[i] : make_double2(0.0, 0.0);
     const int packed = t.nl_cnt[tid];
     const int nn_all = list_rows(packed);
     // the first rows are requested together with the count (at 32 lanes per particle a lane rarely owns more than
@@ -2127,30 +1979,19 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     const bool lead = in_cap && sub == 0;
     const double4 a_own = lead ? t.a[i] : make_double4(0.0, 0.0, 0.0, 0.0);
     const double rhoh_i = a_own.z;
-    double2 pn = (!WALK && lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
+    const double2 pn = (lead && do_hist) ? t.posn[i] : make_double2(0.0, 0.0);  // (requested whenever a histogram is possible)
     const TileMap layout = (WALK && TILE > 0) ? tile_map_of(t, blk) : TileMap{0, 0, 0, 0, 0, 0};
-    // (dt is needed after the walk only.  The compact forms publish their maximum BEFORE the walk, after which the tail may
-    //  advance the clock: they take dt now; the large-channel forms publish at the end, so the clock cannot move before this
-    //  workgroup is through with it, and they read dt where they use it -- one value less to carry through the walk, in kernels
-    //  that sit exactly at their register budget)
-    const double dt_early = WALK ? 0.0 : clk->dt;
+    const double dt = clk->dt;
     const bool want_out = !WALK || step_outputs_wanted(clk, t);
     const int cell_own = (g.own_by_cell && lead) ? s.cell[i] : 0;
     if (!clk->run[q]) return;
     const int n_now = clk->n;
     const bool active = i < n_now;
     double rate = 0.0;
+    const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
     // do_hist: 1 = this step re-bins (static schedule); 100 + K = dynamic context: the K-th step since the last re-binning will
     // re-bin whatever the drift says, so its histogram can be taken here (k_bin then skips)
     const bool hist = do_hist == 1 || (do_hist >= 100 && clk->pos_count >= do_hist - 101);
-    // ... and exactly on those steps of a dynamic context the passes find / leave the new state in the temporaries (FluidTmp::sched_off)
-    const int in_off = (WALK && hist && (t.has_slack & kSchedRedirect)) ? (1 + q) * t.cap : 0;
-    const double2 *const veln = t.veln + in_off;
-    if (WALK) {
-        if (in_cap) vi = veln[i];
-        if (lead && do_hist) pn = t.posn[in_off + i];
-    }
-    const double xi = pi.x, yi = pi.y, vxi = vi.x, vyi = vi.y;
     // Tiled form: the cell histogram goes through LDS.  A particle's new cell lies within a cell or two of the workgroup's old
     // ones, so the workgroup counts into a window of kHistCols x kHistRows cells around its first particle's cell with LDS
     // atomics and adds the window to the global histogram once -- 6 M global atomics, ~60 per cell and step, were 135 us of the
@@ -2201,7 +2042,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
             for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
                 const int k = tm.index(sl);
                 c_pos[sl] = s.pos[k];
-                c_vel[sl] = veln[k];
+                c_vel[sl] = t.veln[k];
                 c_vol[sl] = t.vol[k];
             }
             __syncthreads();
@@ -2211,7 +2052,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
                 const int slot = tm.slot(k);
                 if (slot >= 0) { pj = lds_double2(c_pos, slot); vj = lds_double2(c_vel, slot); Volj = lds_double(c_vol, slot); return; }
             }
-            pj = s.pos[k]; vj = veln[k]; Volj = t.vol[k];
+            pj = s.pos[k]; vj = t.veln[k]; Volj = t.vol[k];
         };
         auto term = [&](double dx, double dy, double ujx, double ujy, double Volj) {
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
@@ -2221,7 +2062,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
         auto fetch_code = [&](int e, double2 &pj, double2 &vj, double &Volj) {  // (CODED)
             if (e < kSlotCodes) { pj = lds_double2(c_pos, e); vj = lds_double2(c_vel, e); Volj = lds_double(c_vol, e); return; }
             const int k = wrap_index(i + e - kCodeBias, n_now);
-            pj = s.pos[k]; vj = veln[k]; Volj = t.vol[k];
+            pj = s.pos[k]; vj = t.veln[k]; Volj = t.vol[k];
         };
         const bool seam = __any(active && near_seam(g, xi));
         if (CODED && seam)
@@ -2267,7 +2108,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
                 vj = make_double2(2.0 * wj.y - vxi, 2.0 * wj.z - vyi);  // mirrored wall velocity
             } else {
                 Volj = t.vol[k];
-                vj = veln[k];
+                vj = t.veln[k];
             }
             const double dx = min_image(g, xi - pj.x), dy = yi - pj.y;
             const double r2 = dx * dx + dy * dy, inv_r = rsqrt_nr(r2), r = r2 * inv_r;
@@ -2280,10 +2121,9 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
     if (active && sub == 0) {
         const double rhoh = rhoh_i;
         const double drho_new = rate * rhoh;
-        const double dt = WALK ? clk->dt : dt_early;
         double rho = rhoh + drho_new * (0.5 * dt);
         if (rho < 1e-10) rho = ph.rho0;
-        t.drhon[in_off + i] = drho_new;
+        t.drhon[i] = drho_new;
         if (want_out) {
             t.rho_out[i] = rho;
             t.p_out[i] = eos_pressure(rho, ph.rho0, ph.p0);
@@ -2326,23 +2166,16 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
 // (waves_per_eu: the large-channel forms of passes E and A fit eight waves per SIMD by their vector registers (62-67) but took 106
 //  scalar registers -- seven waves; they are latency-bound, the eighth wave is worth 9 % of pass E at 6 M particles.  Asked for,
 //  the compiler finds a 78-SGPR allocation without spills.)
-// (The large-channel forms are instantiated per tail.  The clock tail holds a whole Clock in registers; in a kernel compiled for
-//  eight waves per SIMD -- 64 VGPRs, one of them taken by spilled scalars -- it, not the pass, decides whether anything goes to
-//  scratch memory, and a kernel with scratch pays for it in every wave.)
-// TAILS: which tail the launch may carry -- 0 none, 1 the clock (continuity_tail), 2 a slab's local maxima (slab_seal_tail),
-// 3 either (decided by `tail` at run time: the compact kernels, which have registers to spare)
-template <int LPP, bool WALK, int TILE, bool CODED = false, int TAILS = 3>
+template <int LPP, bool WALK, int TILE, bool CODED = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WALK ? 8 : 1))) void k_continuity(Clock *clk, int q, Grid g, Phys ph,
                                                        FluidSet s, FluidTmp t, Walls w, int do_hist, int tail, int next_half)
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots], c_vel[kSlots];
     __shared__ double c_vol[kSlots];
-    if (TAILS == 0) tail = 0;
-    else if (TAILS != 3) tail = tail ? TAILS : 0;
     const int nb = (int)gridDim.x - (tail ? 1 : 0);
-    if (TAILS != 0 && tail && (int)blockIdx.x == nb) {
-        if (TAILS == 2 || (TAILS == 3 && tail == 2)) slab_seal_tail(clk, q, t, nb);
+    if (tail && (int)blockIdx.x == nb) {
+        if (tail == 2) slab_seal_tail(clk, q, t, nb);
         else continuity_tail(clk, q, ph, t, nb);
         return;
     }
@@ -2478,33 +2311,29 @@ constexpr int kMaxTile = 4096;
 __global__ __launch_bounds__(kScanBlock) void k_max_tiles(const Clock *clk, int q, int n, const double *a, const double *b,
                                                           double *out_a, double *out_b)
 {
-    // b (optional): the per-workgroup drift pairs, [0, n) the largest, [n, 2 n) the second largest (publish_drift_top2) ->
-    // out_b in the same form over the gridDim.x tiles
     if (!clk->run[q]) return;
     const int base = blockIdx.x * kMaxTile;
-    double m = 0.0, d = 0.0, e = 0.0;
+    double m = 0.0, d = 0.0;
     for (int k = base + threadIdx.x; k < min(base + kMaxTile, n); k += kScanBlock) {
         m = fmax(m, a[k]);
-        if (b) top2_merge(d, e, b[k], b[n + k]);
+        if (b) d = fmax(d, b[k]);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    wave_top2_pairs(d, e);
-    __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64], s_e[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; s_e[threadIdx.x >> 6] = e; }
+    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); d = fmax(d, __shfl_xor(d, off)); }
+    __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); top2_merge(d, e, s_d[k], s_e[k]); }
+        for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
         out_a[blockIdx.x] = m;
-        if (b) { out_b[blockIdx.x] = d; out_b[gridDim.x + blockIdx.x] = e; }
+        if (b) out_b[blockIdx.x] = d;
     }
 }
 
 // Step kernel 5: finish the clock of this step (vmax -> next dt, t += dt, stop test) and scan the
 // cell histogram (small grids) or the tile sums (big grids).  Single block.
 //   vmax_global: slab mode -- the all-reduced max |v| replaces the local reduction.
-//   dpart / rebuilt / half_skin: displacement bookkeeping of grids that are rebuilt only every few steps; dpart holds the drift
-//   pairs of n_vpart workgroups or tiles ([0, n_vpart) the largest squared drift, [n_vpart, 2 n_vpart) the second largest).
+//   dpart / rebuilt / half_skin: displacement bookkeeping of grids that are rebuilt only every few steps.
 //   slab_counters: slab mode -- the keep/left/right counters of k_slab_pack, zeroed for the next step (the unpack
 //   kernel of this step has read them).  vpart_reset: see continuity_tail.
 __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Phys ph, int n_vpart,
@@ -2525,26 +2354,24 @@ __global__ __launch_bounds__(kScanBlock) void k_clock_scan(Clock *clk, int q, Ph
         if (n_new) nn = *n_new;
         if (vmax_global) vg = *vmax_global;
     }
-    double m = 0.0, d = 0.0, e = 0.0;
+    double m = 0.0, d = 0.0;
     if (!vmax_global)
         for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) m = fmax(m, vpart[k]);
     if (dpart)
-        for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) top2_merge(d, e, dpart[k], dpart[n_vpart + k]);
+        for (int k = threadIdx.x; k < n_vpart; k += kScanBlock) d = fmax(d, dpart[k]);
     if (!clk->run[q]) {
         if (threadIdx.x == 0) clk->run[1 - q] = 0;
         return;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    wave_top2_pairs(d, e);
-    __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64], s_e[kScanBlock / 64];
-    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; s_e[threadIdx.x >> 6] = e; }
+    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); d = fmax(d, __shfl_xor(d, off)); }
+    __shared__ double s_m[kScanBlock / 64], s_d[kScanBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); top2_merge(d, e, s_d[k], s_e[k]); }
+        for (int k = 1; k < kScanBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
         // max of sqrt == sqrt of max (monotone, correctly rounded)
-        clock_step(clk, c0, q, ph, vmax_global ? vg : sqrt(m), fl, nn, dpart ? sqrt(d) : -1.0, rebuilt, half_skin, dyn_K,
-                   dpart ? sqrt(e) : -1.0);
+        clock_step(clk, c0, q, ph, vmax_global ? vg : sqrt(m), fl, nn, dpart ? sqrt(d) : -1.0, rebuilt, half_skin, dyn_K);
         if (slab_counters) { slab_counters[0] = 0; slab_counters[1] = 0; slab_counters[2] = 0; }  // pack counters of the next step
     }
     // contexts whose move steps use the tail workgroup of pass E expect "empty" entries before every pass E
@@ -2561,10 +2388,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_only(const Clock *clk, int 
 
 // Step kernel 6: place every particle index into its cell range (arrival order, made canonical by
 // k_reorder).  atomicSub counts the histogram back down to zero, ready for the next step.
-// id_src / pid (optional): the particle's id goes into pid beside its index in perm, so that k_reorder ranks a cell by
-// reading ONE contiguous run instead of chasing perm[k] -> id[perm[k]] (two dependent loads per cell mate)
 __global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int n_fixed, const int *cellid,
-                                                    int *count, const int *start_next, int *perm, const int *id_src, int *pid)
+                                                    int *count, const int *start_next, int *perm)
 {
     if (clk && !slot_active(clk, q)) return;
     const int n = clk ? clk->n : n_fixed;
@@ -2578,7 +2403,6 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int
         const int i = base + (int)threadIdx.x;
         const bool live = i < n;
         const int c = live ? cellid[i] : -1;
-        const int my_id = (live && pid) ? id_src[i] : 0;
         unsigned long long todo = __ballot(live);
         while (todo) {
             const int lead = __ffsll((long long)todo) - 1;
@@ -2589,9 +2413,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const Clock *clk, int q, int
                 int first = 0;
                 if (rank == 0) first = atomicSub(&count[c], cnt);  // returns the count before: slots first-cnt .. first-1
                 first = __shfl(first, __ffsll((long long)same) - 1);
-                const int at = start_next[c] + first - 1 - rank;
-                perm[at] = i;
-                if (pid) pid[at] = my_id;
+                perm[start_next[c] + first - 1 - rank] = i;
             }
             todo &= ~same;
         }
@@ -2611,12 +2433,6 @@ struct ReorderArgs {
     int *src_of;
     int *cell_dst;  // binned cell of every destination slot (nullptr: not needed, walls)
     int *slot_of_id;  // skinned slabs: particle id -> its slot in the new ordering (nullptr: not needed)
-    const int *pid;   // ids in perm order (k_scatter), nullptr: look them up through perm
-    // Dynamic contexts whose passes redirect the new state on scheduled re-binnings (FluidTmp::sched_off): the state fields
-    // (src2[0..1] / dst2[0..1] = pos, vel; src1[0] / dst1[0] = drho; src2[2] = pos once more for posb) are given for the
-    // drift-triggered case (state in the arrays, gather into the temporaries, copy back); when the clock says rebuild_now == 2
-    // (scheduled) source and destination trade places: the passes wrote the temporaries, the gather fills the arrays.
-    int swap_on_scheduled;
 };
 
 // Step kernel 7: canonical rank inside the cell (ascending particle id -> an order that does not
@@ -2627,37 +2443,23 @@ __global__ __launch_bounds__(kBlock) void k_reorder(const Clock *clk, int q, int
 {
     if (clk && !slot_active(clk, q)) return;
     const int n = clk ? clk->n : n_fixed;
-    const bool sw = a.swap_on_scheduled && clk && clk->rebuild_now == 2;
-    const double2 *const pos_s = sw ? a.dst2[0] : a.src2[0], *const vel_s = sw ? a.dst2[1] : a.src2[1];
-    double2 *const pos_d = sw ? const_cast<double2 *>(a.src2[0]) : a.dst2[0], *const vel_d = sw ? const_cast<double2 *>(a.src2[1]) : a.dst2[1];
-    const double *const drho_s = sw ? a.dst1[0] : a.src1[0];
-    double *const drho_d = sw ? const_cast<double *>(a.src1[0]) : a.dst1[0];
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const int c = cellid[i];
         const int lo = start_next[c], hi = start_next[c + 1];
         const int my_id = a.id_src[i];
         int rank = 0;
-        if (a.pid) {
-            for (int k = lo; k < hi; ++k) {
-                const int oid = a.pid[k];
-                rank += (oid < my_id || (oid == my_id && perm[k] < i)) ? 1 : 0;  // tie (periodic images in a slab): by slot
-            }
-        } else {
-            for (int k = lo; k < hi; ++k) {
-                const int o = perm[k];
-                const int oid = a.id_src[o];
-                rank += (oid < my_id || (oid == my_id && o < i)) ? 1 : 0;
-            }
+        for (int k = lo; k < hi; ++k) {
+            const int o = perm[k];
+            const int oid = a.id_src[o];
+            rank += (oid < my_id || (oid == my_id && o < i)) ? 1 : 0;  // tie (periodic images in a slab): by slot
         }
         const int dst = lo + rank;
-        if (a.n2 > 0) {
-            const double2 p_i = pos_s[i];
-            pos_d[dst] = p_i;
-            if (a.n2 > 2) a.dst2[2][dst] = p_i;  // (the binning position: the same value)
-        }
-        if (a.n2 > 1) vel_d[dst] = vel_s[i];
-        if (a.n1 > 0) drho_d[dst] = drho_s[i];
-        if (a.n1 > 1) a.dst1[1][dst] = a.src1[1][i];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+            if (f < a.n2) a.dst2[f][dst] = a.src2[f][i];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+            if (f < a.n1) a.dst1[f][dst] = a.src1[f][i];
         if (a.n4) a.dst4[0][dst] = a.src4[0][i];
         a.id_dst[dst] = my_id;
         if (a.src_of) a.src_of[dst] = i;
@@ -2677,13 +2479,6 @@ __global__ void k_rebinned(Clock *clk)
 {
     clk->drift = 0.0;
     clk->need_rebuild = 0;
-}
-
-// every workgroup's lane map = the identity (until the first cell sweep has sorted it, see lane_particle); per: kBlock / LPP
-__global__ __launch_bounds__(kBlock) void k_lane_map_identity(size_t n, int per, unsigned char *pm)
-{
-    const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k < n) pm[k] = (unsigned char)(k % (size_t)per);
 }
 
 __global__ __launch_bounds__(kBlock) void k_iota(int n, int *a, int base)
@@ -2878,39 +2673,28 @@ struct CopyBack {
     const int *id_s, *cell_s, *start_s;
     int *id_d, *cell_d, *start_d;
     int n_start;  // ncells + 1
-    // 1: the lean form -- binning positions, cells and cell starts were written in place (nobody reads the old ones during the
-    // re-ordering), so only mass and id come back, and the state only after a DRIFT-triggered re-binning (rebuild_now == 1:
-    // on a scheduled one the gather went straight into the state arrays, see ReorderArgs::swap_on_scheduled)
+    // 1: binning positions, cells and cell starts were written in place -- nobody reads the old ones during the re-ordering, so
+    // k_scan_* and k_reorder can take the layout's own arrays as their destination -- and only what the re-ordering itself reads
+    // while it writes (state, mass, id) went through temporaries: 52 bytes per particle to bring back instead of 72
     int lean;
 };
 __global__ __launch_bounds__(kBlock) void k_copyback(const Clock *clk, int qf, CopyBack a)
 {
     if (!slot_active(clk, qf)) return;
     const int n = clk->n;
-    if (a.lean) {
-        const bool state = clk->rebuild_now == 1;
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-            a.mass_d[i] = a.mass_s[i];
-            a.id_d[i] = a.id_s[i];
-            if (state) {
-                a.pos_d[i] = a.pos_s[i];
-                a.vel_d[i] = a.vel_s[i];
-                a.drho_d[i] = a.drho_s[i];
-            }
-        }
-        return;
-    }
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < max(n, a.n_start); i += gridDim.x * kBlock) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < (a.lean ? n : max(n, a.n_start)); i += gridDim.x * kBlock) {
         if (i < n) {
             a.pos_d[i] = a.pos_s[i];
             a.vel_d[i] = a.vel_s[i];
-            a.posb_d[i] = a.posb_s[i];
             a.drho_d[i] = a.drho_s[i];
             a.mass_d[i] = a.mass_s[i];
             a.id_d[i] = a.id_s[i];
-            a.cell_d[i] = a.cell_s[i];
+            if (!a.lean) {
+                a.posb_d[i] = a.posb_s[i];
+                a.cell_d[i] = a.cell_s[i];
+            }
         }
-        if (i < a.n_start) a.start_d[i] = a.start_s[i];
+        if (!a.lean && i < a.n_start) a.start_d[i] = a.start_s[i];
     }
 }
 
@@ -3285,6 +3069,64 @@ __global__ __launch_bounds__(kBlock) void k_slab_unpack3(Clock *clk, int q, Grid
     clk->n = peek(n_new);  // from here on the re-binning chain works on the new particle count
     p.counters[0] = 0; p.counters[1] = 0; p.counters[2] = 0;
     L.send_cnt[0] = 0; L.send_cnt[1] = 0;
+}
+
+// The local maxima a skinned slab feeds into the step's all-reduce -- max |v| of the kicked velocities and max drift of the
+// owned particles -- as a kernel of its own on the slab's SECOND stream: both exist once pass CD is through, so the reduction
+// and the all-reduce behind it run beside pass E instead of behind it (round 3: a tail workgroup of pass E, the all-reduce
+// exposed on the step's only stream).  out[0..1] = {max |v|, max drift}; a stopped loop reports zeros.
+constexpr int kSlabMaxBlocks = 256;
+__global__ __launch_bounds__(kBlock) void k_slab_maxima(const Clock *clk, int q, Grid g, int n_vpart, const double *dpart,
+                                                        const double2 *veln, const int *cell, double *part, double *out,
+                                                        int *ticket)
+{
+    const bool run = clk->run[q] != 0;
+    double m = 0.0, d = 0.0;
+    if (run) {
+        const int n = clk->n, stride = (int)gridDim.x * kBlock;
+        // (four particles per trip, their loads requested together and unconditionally: the loop is a chain of memory round
+        //  trips -- 23 of them per thread with one particle per trip cost 38 us at 0.76 M particles)
+        for (int i0 = blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += 4 * stride) {
+            int ce[4];
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * stride, n - 1);
+                ce[u] = cell[i];
+                v[u] = veln[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * stride >= n || !owns(g, 0.0, ce[u])) continue;  // (skinned slabs own by the binned column)
+                double v2 = v[u].x * v[u].x + v[u].y * v[u].y;
+                if (v2 != v2) v2 = INFINITY;  // NaN poisons the maximum on purpose
+                m = fmax(m, v2);
+            }
+        }
+        for (int k = blockIdx.x * kBlock + threadIdx.x; k < n_vpart; k += gridDim.x * kBlock) d = fmax(d, dpart[k]);
+    }
+    m = wave_max(m);
+    d = wave_max(d);
+    __shared__ double s_m[kBlock / 64], s_d[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&part[2 * blockIdx.x]), (unsigned long long)__double_as_longlong(m),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&part[2 * blockIdx.x + 1]), (unsigned long long)__double_as_longlong(d),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!last_workgroup_out(ticket, (int)gridDim.x) || threadIdx.x != 0) return;
+    m = 0.0; d = 0.0;
+    for (int b = 0; b < (int)gridDim.x; ++b) {
+        m = fmax(m, __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&part[2 * b]),
+                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        d = fmax(d, __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&part[2 * b + 1]),
+                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    }
+    out[0] = run ? sqrt(m) : 0.0;
+    out[1] = run ? sqrt(d) : 0.0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_slot_of_id(int n, const int *id, int *slot_of_id)

@@ -105,13 +105,6 @@ struct sphx_ctx {
     DevBuf<int> cellid, count, perm, src_of, nl_idx, nl_cnt, sl_idx, sl_cnt, flags, tile;
     DevBuf<int> nl_pk, sl_pk, nl_pk2;  // large-channel kernels: fluid entries as 16-bit index differences (FluidTmp::nl_pk)
     DevBuf<int> tmap;                  // ... and every workgroup's tile layout (FluidTmp::tmap)
-    DevBuf<int> pid;                   // particle ids in perm order (k_scatter -> k_reorder)
-    // Dynamic contexts on the large-channel kernels: the two state parities and the temporaries of pos / vel / drho as ONE
-    // allocation each, [S0 | S1 | T] -- fpos_[0], fpos_[1], posn (...) are windows into it -- so that "the temporaries instead
-    // of the other parity" is an element offset the passes can add (FluidTmp::sched_off)
-    DevBuf<double2> pos3, vel3;
-    DevBuf<double> drho3;
-    bool sched_redirect = false;
     DevBuf<double2> wpos;
     DevBuf<double4> wa;
     DevBuf<int> wid, wstart, wrow_any;
@@ -160,6 +153,13 @@ struct sphx_ctx {
     bool lists_ready = false;
     ncclComm_t comm = nullptr;
     hipEvent_t ev_computed = nullptr, ev_received = nullptr;  // single-process ring: cross-stream ordering
+    // Skinned slabs, native loops: the local maxima and the all-reduce behind them run on a second stream beside pass E
+    // (k_slab_maxima): fork after pass CD (ev_cd), join in front of k_slab_pack3 (ev_ar); ev_max: "my local maxima are out"
+    // (in-process rings, where a kernel stands in for the all-reduce)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_cd = nullptr, ev_ar = nullptr, ev_max = nullptr;
+    DevBuf<double> max_part;
+    DevBuf<int> ticket2;
     // Whole slab steps as ONE replayable graph (sphx_slab_graph_prepare): kSlabGraphSteps steps of the native loop -- kernels,
     // the RCCL calls (sphx_slab_run) or the device-to-device copies and cross-stream dependencies of an in-process ring
     // (sphx_slab_group_run; held by slab 0) -- captured once the loop has run eagerly at least twice
@@ -219,6 +219,11 @@ struct sphx_ctx {
         timer.drop_graph_events();
         if (ev_computed) (void)hipEventDestroy(ev_computed);
         if (ev_received) (void)hipEventDestroy(ev_received);
+        if (stream2) (void)hipStreamSynchronize(stream2);
+        if (ev_cd) (void)hipEventDestroy(ev_cd);
+        if (ev_ar) (void)hipEventDestroy(ev_ar);
+        if (ev_max) (void)hipEventDestroy(ev_max);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (h_clock) (void)hipHostFree(h_clock);
         if (h_pub) (void)hipHostFree(h_pub);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -235,10 +240,8 @@ namespace {
 //  problems on stderr)
 struct DebugSwitches {
     bool no_tail_clock = false, no_fuse_ea = false, no_lds_tiles = false, no_coded_lists = false, no_lazy_out = false, log = false;
-    bool no_lane_sort = false;   // the walkers' lanes take the workgroup's particles in index order (lane_particle stays the identity)
-    bool walk_superset = false;  // measurement (coded-list contexts): pass A sums sigma only, passes B, CD, E walk the superset list
-    bool no_sched_redirect = false;  // dynamic contexts: passes always write the other state parity, every re-binning copies back (round 3)
-    bool no_drift_top2 = false;  // the drift bound on the largest drift alone (d <= skin / 2), as up to round 3
+    bool no_slab_overlap = false;  // skinned slabs: the local maxima from pass E's tail workgroup, the all-reduce on the step's only stream (round 3)
+    bool full_copyback = false;  // dynamic contexts: the in-place re-binning copies the whole layout back (round 3)
     int tail_limit = 0;  // > 0: largest pass (in workgroups) whose clock update rides in pass E's tail workgroup
     int forces_tile = 0;    // 320: the old tile size of the slot-coded force pass
     int tiles_be_from = 0;  // > 0: passes B, E and A stage LDS tiles from this many resident particles (2 lanes per particle)
@@ -256,10 +259,8 @@ const DebugSwitches &debug_switches()
         d.no_coded_lists = has("no_coded_lists");
         d.no_lazy_out = has("no_lazy_out");
         d.log = has("log");
-        d.no_drift_top2 = has("no_drift_top2");
-        d.no_sched_redirect = has("no_sched_redirect");
-        d.walk_superset = has("walk_superset");
-        d.no_lane_sort = has("no_lane_sort");
+        d.no_slab_overlap = has("no_slab_overlap");
+        d.full_copyback = has("full_copyback");
         for (int lim : {1024, 2048, 4096, 8192, 16384})
             if (has(("tail_limit_" + std::to_string(lim)).c_str())) d.tail_limit = lim;
         for (int from : {1, 250000, 500000, 750000, 1000000, 1500000, 3000000})
@@ -394,8 +395,7 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
                 bool done = false;
                 if constexpr (LPP == 2) {
                     if (c->coded_lists) {
-                        if (debug_switches().walk_superset) launch(c, "k_density_walk", k_density_w<LPP, kSlotCodes, true, false>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
-                        else launch(c, "k_density_walk", k_density_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
+                        launch(c, "k_density_walk", k_density_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
                         done = true;
                     }
                 }
@@ -407,14 +407,9 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
         // LDS tiles (tile_ranges): the force pass always; KGC and continuity where measured to pay (lds_tiles_be)
         bool coded = false;  // slot-coded lists (2 lanes per particle, every pass with a tile): the CODED forms of the same kernels
         if constexpr (LPP == 2) coded = c->coded_lists;
-        // measurement (walk_superset): passes B, CD and E on the superset list, with a kernel derivative that vanishes beyond 2h
-        const bool super = coded && debug_switches().walk_superset;
-        FluidTmp tsup = t;
-        tsup.nl_pk = t.sl_pk; tsup.nl_cnt = t.sl_cnt; tsup.nl_idx = t.sl_idx; tsup.nl_cap = t.sl_cap;
         if (!only || only == 2) {
             if constexpr (LPP == 2) {
-                if (super) launch(c, "k_kgc", k_kgc_w<LPP, kSlotCodes, true, true>, gp, bp, clk, q, c->grid, c->phys, s, tsup, c->walls, c->fuse_ea ? 1 : 0);
-                else if (coded) launch(c, "k_kgc", k_kgc_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
+                if (coded) launch(c, "k_kgc", k_kgc_w<LPP, kSlotCodes, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
             }
             if (coded) {}
             else if (c->lds_tiles_be) launch(c, "k_kgc", k_kgc_w<LPP, T>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, c->fuse_ea ? 1 : 0);
@@ -425,8 +420,7 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
                 // (the whole layout, four workgroups per CU: with 320 slots, five per CU, a quarter of the neighbours came from
                 //  global memory in nearly every trip of every wave -- 6 M particles 516 -> 489 us, forces_tile_320 for the old size)
                 if (coded) {
-                    if (super) launch(c, "k_forces", k_forces_w<LPP, kForceSlots, true, true>, gp, bp, clk, q, c->grid, c->phys, s, tsup, c->walls);
-                    else if (debug_switches().forces_tile == 320) launch(c, "k_forces", k_forces_w<LPP, 320, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
+                    if (debug_switches().forces_tile == 320) launch(c, "k_forces", k_forces_w<LPP, 320, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
                     else launch(c, "k_forces", k_forces_w<LPP, kForceSlots, true>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
                 }
             }
@@ -435,21 +429,12 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             else launch(c, "k_forces", k_forces_w<LPP, 0>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls);
         }
         if (!only || only == 4) {
-            // (launches without a tail workgroup get the instantiation without the tails' code: see k_continuity)
-            auto pass_e = [&](auto tile, auto is_coded) {
-                constexpr int TL = decltype(tile)::value;
-                constexpr bool CD = decltype(is_coded)::value;
-                const FluidTmp &te = super ? tsup : t;  // (pass E's kernel derivative vanishes beyond 2h as it is)
-                if (tail == 1) launch(c, name_e, k_continuity<LPP, true, TL, CD, 1>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, tail, 0);
-                else if (tail == 2) launch(c, name_e, k_continuity<LPP, true, TL, CD, 2>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, tail, 0);
-                else launch(c, name_e, k_continuity<LPP, true, TL, CD, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, te, c->walls, do_hist, 0, 0);
-            };
             if constexpr (LPP == 2) {
-                if (coded) pass_e(std::integral_constant<int, kSlotCodes>{}, std::true_type{});
+                if (coded) launch(c, name_e, k_continuity<LPP, true, kSlotCodes, true>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
             }
             if (coded) {}
-            else if (c->lds_tiles_be) pass_e(std::integral_constant<int, T>{}, std::false_type{});
-            else pass_e(std::integral_constant<int, 0>{}, std::false_type{});
+            else if (c->lds_tiles_be) launch(c, name_e, k_continuity<LPP, true, T>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
+            else launch(c, name_e, k_continuity<LPP, true, 0>, ge, bp, c->clock.get(), q, c->grid, c->phys, s, t, c->walls, do_hist, tail, 0);
         }
     }
 }
@@ -488,12 +473,10 @@ void launch_cell_scan(sphx_ctx *c, const Clock *clk, int q, int *start_next)
 void launch_scatter_reorder(sphx_ctx *c, const Clock *clk, int q, const ReorderArgs &ra, const FluidSet &d, int max_blocks = 0)
 {
     const dim3 g1(max_blocks > 0 ? std::min(c->n_blocks_flat, max_blocks) : c->n_blocks_flat), bp(kBlock);
-    ReorderArgs rb = ra;
-    rb.pid = c->pid.get();
     launch(c, "k_scatter", k_scatter, g1, bp, clk, q, 0, (const int *)c->cellid.get(), c->count.get(), (const int *)d.start,
-           c->perm.get(), ra.id_src, c->pid.get());
+           c->perm.get());
     launch(c, "k_reorder", k_reorder, g1, bp, clk, q, 0, (const int *)c->cellid.get(), (const int *)d.start,
-           (const int *)c->perm.get(), rb);
+           (const int *)c->perm.get(), ra);
 }
 
 template <int LPP>
@@ -634,8 +617,6 @@ void launch_step_dyn(sphx_ctx *c, int q)
     const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
     FluidTmp t = c->tmp;
     t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
-    // (sched_redirect: on a scheduled re-binning the passes write the temporaries instead, (1 + q) * cap elements further on --
-    //  kSchedRedirect in t.has_slack, Clock::sched_K)
     launch_physics_any(c, q, s, t, 100 + c->rebuild_every, 0, 3);
     const double *vsrc = c->vpart.get(), *dsrc = c->dpart.get();
     int n_red = c->n_vpart;
@@ -650,19 +631,16 @@ void launch_step_dyn(sphx_ctx *c, int q)
     const int qf = q | kOnlyIfRebuild;
     const int kDynBlocks = 4096;  // grid-stride kernels: a launch that skips costs ~3 us instead of an empty 24k-block grid
     const dim3 g1(std::min(c->n_blocks_flat, kDynBlocks)), bp(kBlock);
-    // Re-binning in place.  Temporaries: the tmp state arrays and the (otherwise unused) second layout.  The lean form
-    // (sched_redirect) writes what nobody reads during the re-ordering -- binning positions, cells, cell starts -- straight into
-    // the layout, gathers the state straight into the state arrays when the re-binning was a scheduled one (the passes wrote the
-    // temporaries, FluidTmp::sched_off), and copies back mass and id only (+ the state after a drift-triggered re-binning).
-    const bool lean = c->sched_redirect;
+    // Re-binning in place.  Temporaries: the tmp state arrays and the (otherwise unused) second layout's mass and id.  What
+    // nobody reads during the re-ordering -- binning positions, cells, cell starts -- is written straight into the layout
+    // (round 4: 52 instead of 72 bytes per particle to copy back; SPHX_DEBUG_SWITCHES=full_copyback for the old form).
+    const bool lean = !debug_switches().full_copyback;
     const FluidSet d{c->posn.get(), c->veln.get(), c->drhon.get(), c->fmass_[1].get(), c->fid_[1].get(),
                      lean ? o.start : c->fstart_[1].get(), lean ? o.cell : c->fcell_[1].get(), lean ? o.posb : c->fposb_[1].get()};
     launch(c, "k_bin", k_bin, g1, bp, (const Clock *)clk, qf | kOnlyIfNoHistogram, c->grid, 0, (const double2 *)o.pos,
            c->cellid.get(), c->count.get());  // drift-triggered re-binnings only: pass E bins on the scheduled ones
     launch_cell_scan(c, clk, qf, d.start);
-    ReorderArgs ra = reorder_args(o.pos, o.vel, o.drho, s.mass, s.id, d, c->tmp.src_of);
-    ra.swap_on_scheduled = lean ? 1 : 0;
-    launch_scatter_reorder(c, clk, qf, ra, d, kDynBlocks);
+    launch_scatter_reorder(c, clk, qf, reorder_args(o.pos, o.vel, o.drho, s.mass, s.id, d, c->tmp.src_of), d, kDynBlocks);
     CopyBack cb{d.pos, d.vel, d.posb, o.pos, o.vel, o.posb, d.drho, d.mass, o.drho, o.mass, d.id, d.cell, d.start,
                 o.id, o.cell, o.start, c->grid.ncells + 1, lean ? 1 : 0};
     launch(c, "k_copyback", k_copyback, g1, bp, (const Clock *)clk, qf, cb);
@@ -879,7 +857,7 @@ void forced_rebuild(sphx_ctx *c)
                        c->count.get());
     launch_cell_scan(c, nullptr, 0, d.start);
     hipLaunchKernelGGL(k_scatter, g1, bp, 0, st, (const Clock *)nullptr, 0, n, (const int *)c->cellid.get(), c->count.get(),
-                       (const int *)d.start, c->perm.get(), (const int *)nullptr, (int *)nullptr);
+                       (const int *)d.start, c->perm.get());
     // src_of: new slot -> slot of the layout the last step's outputs (rho, p, force, Vol, B) are stored in
     hipLaunchKernelGGL(k_reorder, g1, bp, 0, st, (const Clock *)nullptr, 0, n, (const int *)c->cellid.get(),
                        (const int *)d.start, (const int *)c->perm.get(),
@@ -954,7 +932,7 @@ void initial_sort(sphx_ctx *c, const Grid &g, int n, const double2 *pos, int *ce
     hipLaunchKernelGGL(k_bin, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, g, n, pos, cellid, count);
     hipLaunchKernelGGL(k_scan_only, dim3(1), dim3(kScanBlock), 0, s, (const Clock *)nullptr, 0, (const int *)count, start, g.ncells);
     hipLaunchKernelGGL(k_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
-                       (const int *)cellid, count, (const int *)start, perm, (const int *)nullptr, (int *)nullptr);
+                       (const int *)cellid, count, (const int *)start, perm);
     hipLaunchKernelGGL(k_reorder, dim3(div_up(n, kBlock)), dim3(kBlock), 0, s, (const Clock *)nullptr, 0, n,
                        (const int *)cellid, (const int *)start, (const int *)perm, ra);
     SPHX_HIP(hipGetLastError());
@@ -979,25 +957,13 @@ void ctx_alloc(sphx_ctx *c, int cap)
     c->cap = cap;
     c->n_blocks_particles = (int)div_up((size_t)cap * c->lpp, kBlock);
     c->n_blocks_flat = (int)div_up((size_t)cap, kBlock);
-    c->sched_redirect = c->dyn && c->walk_kernels && !debug_switches().no_sched_redirect;
-    if (c->sched_redirect) {
-        const size_t z = (size_t)cap;
-        c->pos3.alloc(3 * z); c->vel3.alloc(3 * z); c->drho3.alloc(3 * z);
-        for (int k = 0; k < 2; ++k) {
-            c->fpos_[k].view(c->pos3.get() + k * z, z); c->fvel_[k].view(c->vel3.get() + k * z, z);
-            c->fdrho_[k].view(c->drho3.get() + k * z, z);
-        }
-        c->posn.view(c->pos3.get() + 2 * z, z); c->veln.view(c->vel3.get() + 2 * z, z); c->drhon.view(c->drho3.get() + 2 * z, z);
-    }
     for (int k = 0; k < 2; ++k) {
-        if (!c->sched_redirect) { c->fpos_[k].alloc(cap); c->fvel_[k].alloc(cap); c->fdrho_[k].alloc(cap); }
-        c->fmass_[k].alloc(cap);
+        c->fpos_[k].alloc(cap); c->fvel_[k].alloc(cap); c->fdrho_[k].alloc(cap); c->fmass_[k].alloc(cap);
         c->fid_[k].alloc(cap); c->fstart_[k].alloc((size_t)g.ncells + 1); c->fcell_[k].alloc(cap);
         if (c->skin > 0.0) c->fposb_[k].alloc(cap);
     }
-    if (!c->sched_redirect) { c->posn.alloc(cap); c->veln.alloc(cap); c->drhon.alloc(cap); }
-    c->pid.alloc(cap);
-    c->ffp.alloc(cap); c->ff.alloc(cap); c->fa.alloc(cap); c->fB.alloc(cap); c->rho_out.alloc(cap); c->p_out.alloc(cap); c->fvol.alloc(cap); c->fvol.zero(c->stream);
+    c->posn.alloc(cap); c->veln.alloc(cap); c->ffp.alloc(cap); c->ff.alloc(cap); c->fa.alloc(cap); c->fB.alloc(cap);
+    c->drhon.alloc(cap); c->rho_out.alloc(cap); c->p_out.alloc(cap); c->fvol.alloc(cap); c->fvol.zero(c->stream);
     c->posn.zero(c->stream); c->veln.zero(c->stream); c->ffp.zero(c->stream); c->ff.zero(c->stream);
     c->fa.zero(c->stream); c->fB.zero(c->stream); c->drhon.zero(c->stream); c->rho_out.zero(c->stream); c->p_out.zero(c->stream);
     c->n_vpart = c->n_blocks_particles;
@@ -1008,10 +974,10 @@ void ctx_alloc(sphx_ctx *c, int cap)
     // (skinned slabs: the same hand-over feeds slab_seal_tail)
     const bool vpart_flags = c->tail_clock || (c->is_slab && c->rebuild_every > 1);
     SPHX_HIP(hipMemsetAsync(c->vpart.get(), vpart_flags ? 0xFF : 0, (size_t)c->n_vpart * sizeof(double), c->stream));
-    c->dpart.alloc(2 * (size_t)c->n_vpart);  // (the two largest squared drifts per workgroup, see publish_drift_top2)
+    c->dpart.alloc(c->n_vpart);
     c->dpart.zero(c->stream);
     c->n_vtiles = (!c->is_slab && c->n_vpart > 4 * kMaxTile) ? (int)div_up((size_t)c->n_vpart, kMaxTile) : 0;
-    if (c->n_vtiles) c->vtile.alloc(3 * (size_t)c->n_vtiles);  // max |v|^2, then the drift pairs
+    if (c->n_vtiles) c->vtile.alloc(2 * (size_t)c->n_vtiles);
     c->cellid.alloc(cap); c->count.alloc((size_t)g.ncells + 1); c->perm.alloc(cap); c->src_of.alloc(cap);
     c->count.zero(c->stream);
     const int nl_cap = nl_cap_for(c->lpp);
@@ -1038,20 +1004,13 @@ void ctx_alloc(sphx_ctx *c, int cap)
                       c->rho_out.get(), c->p_out.get(), c->cellid.get(), c->count.get(), c->perm.get(), c->src_of.get(),
                       c->vpart.get(), c->dpart.get(), c->nl_idx.get(), c->nl_cnt.get(), c->flags.get(), c->tile.get(),
                       (int)stride, nl_cap, c->sl_idx.get(), c->sl_cnt.get(), sl_cap, sl_r * sl_r, cap, c->n_vpart,
-                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(),
-                      (c->is_slab ? kSlack : 0) | (debug_switches().no_drift_top2 ? kDriftTop1 : 0) | (c->sched_redirect ? kSchedRedirect : 0) |
-                          (debug_switches().no_lane_sort ? kNoLaneSort : 0),
-                      nullptr, 0, nullptr};
+                      c->skin > 0.0 ? c->half_skin() : -1.0, c->fvol.get(), c->nl_pk.get(), c->sl_pk.get(), c->is_slab ? 1 : 0, nullptr, 0, nullptr};
     // (2 = never: a slab hands out its state only, sphx_slab_snapshot; the dual-rate loop, which reads force_prior in its
     //  inner sub-steps, runs on the compact kernels only)
     c->tmp.lazy_out = (c->walk_kernels && !debug_switches().no_lazy_out) ? (c->is_slab ? 2 : 1) : 0;
     if (c->walk_kernels) {  // (zeros = empty layouts until the first cell sweep has run)
-        // 8 ints of layout per workgroup, then one byte per particle slot: the walkers' lane assignment (lane_particle)
-        const size_t n_slots = (size_t)c->n_blocks_particles * (kBlock / c->lpp);
-        c->tmap.alloc(8 * (size_t)c->n_blocks_particles + (n_slots + 3) / 4); c->tmap.zero(c->stream);
+        c->tmap.alloc(8 * (size_t)c->n_blocks_particles); c->tmap.zero(c->stream);
         c->tmp.tmap = c->tmap.get();
-        hipLaunchKernelGGL(k_lane_map_identity, dim3(div_up(n_slots, kBlock)), dim3(kBlock), 0, c->stream, n_slots, kBlock / c->lpp,
-                           reinterpret_cast<unsigned char *>(c->tmap.get() + 8 * (size_t)c->n_blocks_particles));
     }
     // E|A fusion: small static-schedule channels on the compact kernels (the clock rides in the tail workgroup)
     c->fuse_ea = c->tail_clock && (c->lpp >= 16 || (c->walk_kernels && !c->lds_tiles_be && c->lpp >= 2)) && !debug_switches().no_fuse_ea;
@@ -1142,8 +1101,7 @@ void init_clock(sphx_ctx *c, int n, double t0, int64_t step0)
     k.drift = 0.0; k.need_rebuild = 0;
     k.fresh = 1; k.rebuild_now = 0; k.pos_count = 0; k.n_drift_rebuilds = 0;
     k.seq = 0;
-    k.n_in = (short)c->n_in;
-    k.sched_K = (short)(c->sched_redirect ? c->rebuild_every : 0);
+    k.n_in = c->n_in;
     if (!c->h_pub) SPHX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_pub), sizeof(Clock), hipHostMallocMapped));
     void *pub_dev = nullptr;
     SPHX_HIP(hipHostGetDevicePointer(&pub_dev, c->h_pub, 0));
@@ -2174,6 +2132,15 @@ void slab_native_buffers(sphx_ctx *c)
     c->msg_sl.alloc(n); c->msg_sr.alloc(n); c->msg_rl.alloc(n); c->msg_rr.alloc(n);
     c->vmax_l.alloc(2); c->vmax_g.alloc(2);
     for (DevBuf<double> *b : {&c->msg_sl, &c->msg_sr, &c->msg_rl, &c->msg_rr, &c->vmax_l, &c->vmax_g}) b->zero(c->stream);
+    if (c->rebuild_every > 1 && !debug_switches().no_slab_overlap) {  // the second stream of a skinned slab (k_slab_maxima)
+        SPHX_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        SPHX_HIP(hipEventCreateWithFlags(&c->ev_cd, hipEventDisableTiming));
+        SPHX_HIP(hipEventCreateWithFlags(&c->ev_ar, hipEventDisableTiming));
+        SPHX_HIP(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
+        c->max_part.alloc(2 * kSlabMaxBlocks); c->max_part.zero(c->stream);
+        c->ticket2.alloc(1); c->ticket2.zero(c->stream);
+    }
+    SPHX_HIP(hipStreamSynchronize(c->stream));
 }
 
 // End a capture that went wrong and drop whatever it produced.
@@ -2428,6 +2395,36 @@ void slab_phase1(sphx_ctx *c)  // passes A..E into S[1-q]; the tail workgroup of
     launch_physics_any(c, q, s, t, 0, 0, 3, 2);
 }
 
+// ... in three pieces (contexts with a second stream, see sphx_ctx::stream2): passes A, B, CD on the slab's stream; the local
+// maxima -- both exist once pass CD is through -- on `aux`, where the all-reduce follows them; pass E, without a tail, on the
+// slab's stream again, beside the two
+void slab_phase1_abc(sphx_ctx *c)
+{
+    const int q = c->cur;
+    const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
+    FluidTmp t = c->tmp;
+    t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+    launch_physics_any(c, q, s, t, 0, 1, 3);
+    launch_physics_any(c, q, s, t, 0, 2);
+    launch_physics_any(c, q, s, t, 0, 3);
+}
+void slab_local_maxima_of_step(sphx_ctx *c, hipStream_t aux)
+{
+    const int q = c->cur;
+    const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
+    hipLaunchKernelGGL(k_slab_maxima, dim3(kSlabMaxBlocks), dim3(kBlock), 0, aux, (const Clock *)c->clock.get(), q, c->grid,
+                       c->n_vpart, (const double *)c->dpart.get(), (const double2 *)o.vel, (const int *)s.cell, c->max_part.get(),
+                       c->vmax_l.get(), c->ticket2.get());
+}
+void slab_phase1_e(sphx_ctx *c)
+{
+    const int q = c->cur;
+    const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
+    FluidTmp t = c->tmp;
+    t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+    launch_physics_any(c, q, s, t, 0, 4);
+}
+
 void slab_phase2(sphx_ctx *c)  // global maxima known: re-binning decision, message A, clock -- one launch
 {
     const int q = c->cur;
@@ -2540,6 +2537,29 @@ struct RcclLoop {
             R.check(R.AllReduce(vl, vg, 1, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
             ring(c->msg_sl.get(), c->msg_sr.get(), c->msg_rl.get(), c->msg_rr.get(), n_msg, ncclDouble);
             slab_finish_impl(c, c->msg_rl.get(), c->msg_rr.get(), vg);
+        } else if (c->stream2 && !serial_aux) {
+            // the maxima and the all-reduce on the second stream, beside pass E
+            slab_phase1_abc(c);
+            SPHX_HIP(hipEventRecord(c->ev_cd, st));
+            SPHX_HIP(hipStreamWaitEvent(c->stream2, c->ev_cd, 0));
+            slab_local_maxima_of_step(c, c->stream2);
+            R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, c->stream2), "ncclAllReduce");
+            SPHX_HIP(hipEventRecord(c->ev_ar, c->stream2));
+            slab_phase1_e(c);
+            SPHX_HIP(hipStreamWaitEvent(st, c->ev_ar, 0));
+            slab_phase2(c);
+            ring_step();
+            slab_phase3(c);
+            slab_phase4(c);
+        } else if (c->stream2) {  // (under stream capture: the same pieces in one chain)
+            slab_phase1_abc(c);
+            slab_local_maxima_of_step(c, st);
+            R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
+            slab_phase1_e(c);
+            slab_phase2(c);
+            ring_step();
+            slab_phase3(c);
+            slab_phase4(c);
         } else {
             slab_phase1(c);
             R.check(R.AllReduce(vl, vg, 2, ncclDouble, ncclMax, c->comm, st), "ncclAllReduce");
@@ -2549,6 +2569,7 @@ struct RcclLoop {
             slab_phase4(c);
         }
     }
+    bool serial_aux = false;  // true under stream capture: everything on the one capturing stream
 };
 
 // ---- all slabs of the ring in one process: the same steps with device-to-device copies and events ----
@@ -2595,6 +2616,35 @@ struct GroupLoop {
     // step of a captured graph: what came before is ordered by the launch, see replay())
     void step(bool entry_waits = true)
     {
+        const bool overlap = skinned && ctxs[0]->stream2 != nullptr;
+        if (overlap) {
+            // passes A, B, CD; the local maxima on every slab's second stream (serial: on the one stream); pass E beside them;
+            // the stand-in for the all-reduce on the second stream once everybody's maxima are out; join in front of pack3
+            auto aux = [&](sphx_ctx *c) { return serial ? c->stream : c->stream2; };
+            for (int r = 0; r < n; ++r) {
+                sphx_ctx *c = ctxs[r];
+                if (entry_waits) wait_others(r, &sphx_ctx::ev_received);
+                slab_phase1_abc(c);
+                if (!serial) {
+                    SPHX_HIP(hipEventRecord(c->ev_cd, c->stream));
+                    SPHX_HIP(hipStreamWaitEvent(c->stream2, c->ev_cd, 0));
+                }
+                slab_local_maxima_of_step(c, aux(c));
+                if (!serial) SPHX_HIP(hipEventRecord(c->ev_max, c->stream2));
+            }
+            for (int r = 0; r < n; ++r) slab_phase1_e(ctxs[r]);
+            for (int r = 0; r < n; ++r) {  // "all-reduce", decision, message A
+                sphx_ctx *c = ctxs[r];
+                if (!serial)
+                    for (int o = 0; o < n; ++o) if (o != r) SPHX_HIP(hipStreamWaitEvent(c->stream2, ctxs[o]->ev_max, 0));
+                hipLaunchKernelGGL(k_max_of, dim3(1), dim3(2), 0, aux(c), n, vls, c->vmax_g.get());
+                if (!serial) {
+                    SPHX_HIP(hipEventRecord(c->ev_ar, c->stream2));
+                    SPHX_HIP(hipStreamWaitEvent(c->stream, c->ev_ar, 0));
+                }
+                slab_phase2(c);
+            }
+        } else {
         for (int r = 0; r < n; ++r) {
             sphx_ctx *c = ctxs[r];
             if (entry_waits) wait_others(r, &sphx_ctx::ev_received);
@@ -2618,6 +2668,7 @@ struct GroupLoop {
             wait_others(r, &sphx_ctx::ev_computed);
             max_of_all(c);
             slab_phase2(c);
+        }
         }
         done(&sphx_ctx::ev_received);  // (reused: "my maxima have been read by me, my message A is complete")
         for (int r = 0; r < n; ++r) {  // message A and the ids of the previous step's lists in
@@ -2788,6 +2839,7 @@ SPHX_EXPORT int sphx_slab_graph_prepare(sphx_ctx **ctxs, int n)
     try {
         if (n == 1) {
             RcclLoop loop(c0);
+            loop.serial_aux = true;
             for (int k = 0; k < kSlabGraphSteps; ++k) loop.step();
         } else {
             GroupLoop loop(ctxs, n);
