@@ -3117,14 +3117,23 @@ __global__ __launch_bounds__(kBlock) void k_slab_maxima(const Clock *clk, int q,
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(&part[2 * blockIdx.x + 1]), (unsigned long long)__double_as_longlong(d),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!last_workgroup_out(ticket, (int)gridDim.x) || threadIdx.x != 0) return;
+    // the last workgroup out folds the partial maxima -- one per thread: a single thread reading them with agent-scope loads
+    // one after the other took 80 us (the compiler does not overlap atomic loads)
+    if (!last_workgroup_out(ticket, (int)gridDim.x)) return;
     m = 0.0; d = 0.0;
-    for (int b = 0; b < (int)gridDim.x; ++b) {
+    for (int b = (int)threadIdx.x; b < (int)gridDim.x; b += kBlock) {
         m = fmax(m, __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&part[2 * b]),
                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
         d = fmax(d, __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&part[2 * b + 1]),
                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
     }
+    m = wave_max(m);
+    d = wave_max(d);
+    __syncthreads();  // (s_m / s_d are reused)
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_d[threadIdx.x >> 6] = d; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int k = 1; k < kBlock / 64; ++k) { m = fmax(m, s_m[k]); d = fmax(d, s_d[k]); }
     out[0] = run ? sqrt(m) : 0.0;
     out[1] = run ? sqrt(d) : 0.0;
 }
