@@ -642,6 +642,21 @@ __device__ __forceinline__ void half_state(const Phys &ph, double rho, double dr
     ph_ = eos_pressure(rhoh, ph.rho0, ph.p0);
 }
 
+// Slabs, frozen steps: pass A of the next step in two launches, so that the halo exchange of this step hides behind the
+// first.  part = 1: only the INTERIOR workgroups -- every particle of theirs binned in the columns [own_c0 + 1, own_c1 - 1),
+// so that their candidates (one column either side) and the tiles they stage lie in owned columns, which the incoming message
+// does not touch -- launched right behind k_slab_pack3; part = 2: the rest (boundary workgroups), behind k_slab_unpack3.
+// part rides in the walk kernels' cond_fresh argument: bits 4 and up (kPassPartShift).
+constexpr int kPassPartShift = 4;
+template <int LPP>
+__device__ __forceinline__ bool slab_part_skips(const Grid &g, const FluidSet &s, int blk, int part)
+{
+    const int first = blk * (kBlock / LPP), last = first + kBlock / LPP - 1;
+    const int lo = s.start[(g.own_c0 + 1) * g.ncy], hi = s.start[(g.own_c1 - 1) * g.ncy];
+    const bool interior = first >= lo && last < hi;
+    return interior != (part == 1);
+}
+
 // cond_fresh (dynamic contexts launch both MODE 1 and MODE 2 on every step): -1 = always run, 1 = only on a fresh grid,
 // 0 = only on a grid that is not fresh.  Measured at 6 M particles, average pass A per step: two launches of which one
 // returns 786 us; one kernel holding both bodies 891 us (it runs at the register budget of the bigger one); one
@@ -650,7 +665,10 @@ template <int LPP, int MODE>
 __global__ __launch_bounds__(kBlock) void k_density(const Clock *clk, int q, Grid g, Phys ph,
                                                     FluidSet s, FluidTmp t, Walls w, int cond_fresh)
 {
+    const int part = cond_fresh >= 0 ? cond_fresh >> kPassPartShift : 0;
+    if (part) cond_fresh &= (1 << kPassPartShift) - 1;
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
+    if (MODE == 2 && part && slab_part_skips<LPP>(g, s, xcd_block((int)blockIdx.x, (int)gridDim.x), part)) return;
     density_body<LPP, MODE>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true);
 }
 
@@ -1464,7 +1482,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((TILE > 
 {
     constexpr int kSlots = TILE > 0 ? TILE : 1;
     __shared__ double2 c_pos[kSlots];
+    const int part = cond_fresh >= 0 ? cond_fresh >> kPassPartShift : 0;  // (see slab_part_skips)
+    if (part) cond_fresh &= (1 << kPassPartShift) - 1;
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
+    if (part && slab_part_skips<LPP>(g, s, xcd_block((int)blockIdx.x, (int)gridDim.x), part)) return;
     density_walk_body<LPP, TILE, CODED>(clk, q, g, ph, s, t, w, (int)blockIdx.x, (int)gridDim.x, true, c_pos);
 }
 

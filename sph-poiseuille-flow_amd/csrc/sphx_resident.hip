@@ -160,6 +160,9 @@ struct sphx_ctx {
     hipEvent_t ev_cd = nullptr, ev_ar = nullptr, ev_max = nullptr;
     DevBuf<double> max_part;
     DevBuf<int> ticket2;
+    hipEvent_t ev_p = nullptr, ev_u = nullptr;  // "message A is packed" / "the halo is refreshed (or the layout rebuilt)"
+    int pass_a_part = 0;           // what the next launch of pass A's walk covers: 0 all, 1 interior, 2 boundary workgroups (slab_part_skips)
+    bool a_interior_done = false;  // the interior workgroups of the coming step's pass A were launched behind this step's pack3
     // Whole slab steps as ONE replayable graph (sphx_slab_graph_prepare): kSlabGraphSteps steps of the native loop -- kernels,
     // the RCCL calls (sphx_slab_run) or the device-to-device copies and cross-stream dependencies of an in-process ring
     // (sphx_slab_group_run; held by slab 0) -- captured once the loop has run eagerly at least twice
@@ -223,6 +226,8 @@ struct sphx_ctx {
         if (ev_cd) (void)hipEventDestroy(ev_cd);
         if (ev_ar) (void)hipEventDestroy(ev_ar);
         if (ev_max) (void)hipEventDestroy(ev_max);
+        if (ev_p) (void)hipEventDestroy(ev_p);
+        if (ev_u) (void)hipEventDestroy(ev_u);
         if (stream2) (void)hipStreamDestroy(stream2);
         if (h_clock) (void)hipHostFree(h_clock);
         if (h_pub) (void)hipHostFree(h_pub);
@@ -360,7 +365,8 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             else {
                 // dmode 2: walk the superset list; 3 (dynamic contexts): build and walk, each skipping itself according to the
                 // clock's `fresh`
-                const int cond = dmode == 2 ? -1 : 0;
+                // (dmode 4, slabs: the walk alone, on a grid that is not fresh; pass_a_part: interior / boundary workgroups only)
+                const int cond = dmode == 2 ? -1 : (c->pass_a_part << kPassPartShift);
                 if (dmode == 3) launch(c, "k_density_build", k_density<LPP, 1>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, 1);
                 launch(c, "k_density_walk", k_density<LPP, 2>, gp, bp, clk, q, c->grid, c->phys, s, t, c->walls, cond);
             }
@@ -390,7 +396,7 @@ void launch_physics(sphx_ctx *c, int q, const FluidSet &s, const FluidTmp &t, in
             if (dmode == 0) sweep("k_density", std::integral_constant<int, 0>{}, -1);
             else if (dmode == 1) sweep("k_density_build", std::integral_constant<int, 1>{}, -1);
             else {
-                const int cond = dmode == 2 ? -1 : 0;
+                const int cond = dmode == 2 ? -1 : (c->pass_a_part << kPassPartShift);  // (dmode 4: see the compact kernels)
                 if (dmode == 3) sweep("k_density_build", std::integral_constant<int, 1>{}, 1);
                 bool done = false;
                 if constexpr (LPP == 2) {
@@ -2137,6 +2143,8 @@ void slab_native_buffers(sphx_ctx *c)
         SPHX_HIP(hipEventCreateWithFlags(&c->ev_cd, hipEventDisableTiming));
         SPHX_HIP(hipEventCreateWithFlags(&c->ev_ar, hipEventDisableTiming));
         SPHX_HIP(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
+        SPHX_HIP(hipEventCreateWithFlags(&c->ev_p, hipEventDisableTiming));
+        SPHX_HIP(hipEventCreateWithFlags(&c->ev_u, hipEventDisableTiming));
         c->max_part.alloc(2 * kSlabMaxBlocks); c->max_part.zero(c->stream);
         c->ticket2.alloc(1); c->ticket2.zero(c->stream);
     }
@@ -2398,15 +2406,35 @@ void slab_phase1(sphx_ctx *c)  // passes A..E into S[1-q]; the tail workgroup of
 // ... in three pieces (contexts with a second stream, see sphx_ctx::stream2): passes A, B, CD on the slab's stream; the local
 // maxima -- both exist once pass CD is through -- on `aux`, where the all-reduce follows them; pass E, without a tail, on the
 // slab's stream again, beside the two
+// pass A of the step slot of parity q on S[q]: dmode 3 = the cell sweep (fresh grid only) and the walk of `part` (0 all,
+// 1 interior, 2 boundary workgroups, see slab_part_skips); dmode 4 = that walk alone
+void slab_pass_a(sphx_ctx *c, int q, int dmode, int part)
+{
+    const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
+    FluidTmp t = c->tmp;
+    t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
+    c->pass_a_part = part;
+    launch_physics_any(c, q, s, t, 0, 1, dmode);
+    c->pass_a_part = 0;
+}
 void slab_phase1_abc(sphx_ctx *c)
 {
     const int q = c->cur;
     const FluidSet s = c->view(q, 0), o = c->view(1 - q, 0);
     FluidTmp t = c->tmp;
     t.posn = o.pos; t.veln = o.vel; t.drhon = o.drho;
-    launch_physics_any(c, q, s, t, 0, 1, 3);
+    // (the interior workgroups of this pass A may have run already, behind the previous step's pack3: slab_pass_a_interior)
+    slab_pass_a(c, q, 3, c->a_interior_done ? 2 : 0);
+    c->a_interior_done = false;
     launch_physics_any(c, q, s, t, 0, 2);
     launch_physics_any(c, q, s, t, 0, 3);
+}
+// message A of the step just taken is packed, the clock advanced, the host's parity flipped (slab_phase4): the interior
+// workgroups of the NEXT step's pass A need nothing the exchange brings -- they run while it is under way
+void slab_pass_a_interior(sphx_ctx *c)
+{
+    slab_pass_a(c, c->cur, 4, 1);
+    c->a_interior_done = true;
 }
 void slab_local_maxima_of_step(sphx_ctx *c, hipStream_t aux)
 {
@@ -2538,7 +2566,8 @@ struct RcclLoop {
             ring(c->msg_sl.get(), c->msg_sr.get(), c->msg_rl.get(), c->msg_rr.get(), n_msg, ncclDouble);
             slab_finish_impl(c, c->msg_rl.get(), c->msg_rr.get(), vg);
         } else if (c->stream2 && !serial_aux) {
-            // the maxima and the all-reduce on the second stream, beside pass E
+            // the maxima and the all-reduce on the second stream, beside pass E; then the exchange and what follows it on the
+            // second stream, beside the interior workgroups of the next step's pass A
             slab_phase1_abc(c);
             SPHX_HIP(hipEventRecord(c->ev_cd, st));
             SPHX_HIP(hipStreamWaitEvent(c->stream2, c->ev_cd, 0));
@@ -2548,9 +2577,18 @@ struct RcclLoop {
             slab_phase1_e(c);
             SPHX_HIP(hipStreamWaitEvent(st, c->ev_ar, 0));
             slab_phase2(c);
-            ring_step();
-            slab_phase3(c);
+            SPHX_HIP(hipEventRecord(c->ev_p, st));
+            SPHX_HIP(hipStreamWaitEvent(c->stream2, c->ev_p, 0));
+            {
+                hipStream_t keep = st;
+                st = c->stream2; c->stream = c->stream2;  // (ring_step and slab_phase3 enqueue on "the" stream)
+                try { ring_step(); slab_phase3(c); } catch (...) { st = keep; c->stream = keep; throw; }
+                st = keep; c->stream = keep;
+            }
+            SPHX_HIP(hipEventRecord(c->ev_u, c->stream2));
             slab_phase4(c);
+            slab_pass_a_interior(c);
+            SPHX_HIP(hipStreamWaitEvent(st, c->ev_u, 0));
         } else if (c->stream2) {  // (under stream capture: the same pieces in one chain)
             slab_phase1_abc(c);
             slab_local_maxima_of_step(c, st);
@@ -2643,6 +2681,12 @@ struct GroupLoop {
                     SPHX_HIP(hipStreamWaitEvent(c->stream, c->ev_ar, 0));
                 }
                 slab_phase2(c);
+                // "my maxima have been read by me, my message A is complete" -- recorded HERE, in front of the interior
+                // workgroups of the next step's pass A, which the neighbours need not wait for (the in-process ring keeps the
+                // copies that stand in for the exchange on the slab's own stream: what it tests is the split itself)
+                if (!serial) SPHX_HIP(hipEventRecord(c->ev_received, c->stream));
+                slab_pass_a(c, 1 - c->cur, 4, 1);
+                c->a_interior_done = true;
             }
         } else {
         for (int r = 0; r < n; ++r) {
@@ -2670,7 +2714,7 @@ struct GroupLoop {
             slab_phase2(c);
         }
         }
-        done(&sphx_ctx::ev_received);  // (reused: "my maxima have been read by me, my message A is complete")
+        if (!overlap) done(&sphx_ctx::ev_received);  // (reused: "my maxima have been read by me, my message A is complete")
         for (int r = 0; r < n; ++r) {  // message A and the ids of the previous step's lists in
             wait_others(r, &sphx_ctx::ev_received);
             copy_msgs(r);
@@ -2704,7 +2748,7 @@ struct GroupLoop {
         SPHX_HIP(hipEventRecord(c0->ev_fork, c0->stream));
         for (int r = 1; r < n; ++r) SPHX_HIP(hipStreamWaitEvent(ctxs[r]->stream, c0->ev_fork, 0));
         done(&sphx_ctx::ev_received);  // (the eager steps that may follow wait for these)
-        for (int r = 0; r < n; ++r) ctxs[r]->slab_steps_enqueued += kSlabGraphSteps;
+        for (int r = 0; r < n; ++r) { ctxs[r]->slab_steps_enqueued += kSlabGraphSteps; ctxs[r]->a_interior_done = false; }
     }
 };
 
@@ -2738,6 +2782,7 @@ SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
     RcclLoop loop(c);
     double *vl = c->vmax_l.get(), *vg = c->vmax_g.get();
     const bool skinned = c->rebuild_every > 1;
+    c->a_interior_done = false;  // (whatever the previous call launched ahead found the loop stopped: the first step sweeps / walks everything)
     // arm the clock with the global max |v| of the current state: after a step the clock holds it already (the all-reduced
     // value that step's dt rule used); only a state that has never been stepped needs the reduction (k_vmax_init is one
     // workgroup over the whole slab: 0.9 ms at 0.76 M particles)
@@ -2758,6 +2803,7 @@ SPHX_EXPORT int sphx_slab_run(sphx_ctx *c, double t_target, int64_t n_steps)
         for (; n_steps - k >= kSlabGraphSteps; k += kSlabGraphSteps) {
             SPHX_HIP(hipGraphLaunch(c->steps_graph, loop.st));
             c->slab_steps_enqueued += kSlabGraphSteps;
+            c->a_interior_done = false;
         }
     for (; k < n_steps; ++k) loop.step();  // ... the rest step by step
     SPHX_HIP(hipGetLastError());
@@ -2771,6 +2817,7 @@ SPHX_EXPORT int sphx_slab_group_run(sphx_ctx **ctxs, int n, double t_target, int
     check_ring(ctxs, n);
     require(n_steps > 0, "SPHX:Ctx:steps", "n_steps must be positive");
     GroupLoop loop(ctxs, n);
+    for (int r = 0; r < n; ++r) ctxs[r]->a_interior_done = false;  // (see sphx_slab_run)
     // arm: local maxima -> global -> clock (a state that has been stepped: the clock holds the global maximum already, see
     // sphx_slab_run); first exchange lists
     bool fresh_state = false;
@@ -2834,6 +2881,7 @@ SPHX_EXPORT int sphx_slab_graph_prepare(sphx_ctx **ctxs, int n)
     std::vector<hipStream_t> own_streams(n);
     for (int r = 0; r < n; ++r) { own_streams[r] = ctxs[r]->stream; ctxs[r]->stream = s0; }
     auto restore_streams = [&]() { for (int r = 0; r < n; ++r) ctxs[r]->stream = own_streams[r]; };
+    for (int r = 0; r < n; ++r) ctxs[r]->a_interior_done = false;  // (the graph's first step sweeps / walks everything)
     const hipError_t e_begin = hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed);
     if (e_begin != hipSuccess) { restore_streams(); SPHX_HIP(e_begin); }
     try {
@@ -2853,7 +2901,7 @@ SPHX_EXPORT int sphx_slab_graph_prepare(sphx_ctx **ctxs, int n)
         throw;
     }
     restore_streams();
-    for (int r = 0; r < n; ++r) ctxs[r]->slab_steps_enqueued -= kSlabGraphSteps;  // nothing has executed
+    for (int r = 0; r < n; ++r) { ctxs[r]->slab_steps_enqueued -= kSlabGraphSteps; ctxs[r]->a_interior_done = false; }  // nothing has executed
     const hipError_t e_end = hipStreamEndCapture(s0, &g);
     if (e_end != hipSuccess) { (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g); SPHX_HIP(e_end); }
     hipGraphExec_t exec = nullptr;
