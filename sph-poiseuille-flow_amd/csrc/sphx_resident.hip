@@ -1213,7 +1213,23 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // 20 k - 250 k particles, K = 5 / 8 / 12 / 16: 28.8 / 27.6 / 27.1 / 27.8 us/step at 21 k, 49.8 / 48.7 / 49.1 / 49.4 at 65 k,
     // 79.5 / 72.1 / 72.6 / 74.8 at 130 k, 142 / 118 / 119 / 121 at 250 k (K = 5: its thin skin forces rebuilds + cool-downs) -> 8;
     // 0.5 M: 189 / 192 at K = 5 / 8, 6 M: 2 201 / 2 262 -> 5.
-    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 16 : (nf <= 300000 ? 8 : 5));
+    // Round 4: the interval and the skin are two things (profiles/r04_k_skin_*.txt).  The skin prices EVERY step (the superset
+    // list grows with it: 1.30 x the neighbours at 0.28 h, 1.55 x at 0.49 h) and, with the drift check, is all that correctness
+    // needs; K only says when a re-binning is taken whether or not the drift asks for one.  Where the device re-bins by itself
+    // (from 10^6 particles) a late scheduled re-binning costs nothing -- the drift bound comes first -- so the skin stays that
+    // of K = 5 and K goes up: C5 1 632 -> 1 507 us/step in bench.py's window at K = 12, 1 723 -> 1 598 sustained (K = 12 with
+    // 0.31 h: 1 514 / 1 603); on another box K = 12 / 16 / 24 / 64: 1 550 / 1 523 / 1 503 / 1 493 in the window, 1 645 sustained for
+    // all four (the drift bound decides there) -> 24.  1.25 M particles 384 -> 354 / 413 -> 401.  On the host-driven schedule a
+    // drift stop is a round trip and a cool-down, so the skin has to grow with K: 0.3-1 M particles K = 10 with 0.42 h (C4 160 ->
+    // 157 in the window, 170 -> 164 sustained, one forced re-binning in 3 000 steps; K = 8 with 0.28 h: 17 of them, 263 us/step).
+    // Up to 20 k particles K = 16 stays: K = 24 on the same skin (1.05 h) is 3 % faster on the bench's flow (C2 17.4 -> 16.8
+    // us/step, C1 14.2 -> 13.7, no forced re-binning in 12 000 developed steps) but a flow AT the reference's U_max drifts
+    // 0.023 h a step -- 23 steps of that are the whole half-skin, and tests/test_gpu_headline_parity.py's state forced 16
+    // re-binnings in 50 steps with it (K = 32: 86 in the bench's own flow, 50 us/step); 20 k - 300 k stays at 8 (every other
+    // pair measured slower there: profiles/r04_k_skin_c3.txt, _194k.txt).
+    const bool dyn_wanted = prm->dynamic_rebin == 1 || (prm->dynamic_rebin == 0 && nf >= 1000000);
+    const bool auto_policy = prm->rebuild_every <= 0 && prm->skin_h <= 0.0;
+    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 16 : (nf <= 300000 ? 8 : (dyn_wanted ? 24 : 10)));
     // dual-rate loop: a slot moves particles n_sub times as far.  Same eligibility as ctx_alloc's n_in (the fused E|A launch
     // with the clock in its tail workgroup: a skin, static schedule, <= 2048 workgroups, compact kernels)
     const bool dual_ok = c->lpp >= 16 && !c->is_slab && K > 1 && prm->dynamic_rebin != 1 &&
@@ -1222,13 +1238,14 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     if (n_sub > 1 && prm->rebuild_every <= 0) K = std::max(2, K / n_sub);
     const double d_step = 0.035 * prm->h * n_sub;
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
+    if (auto_policy && nf > 300000 && K > 1) skin = (dyn_wanted ? 0.28 : 0.42) * prm->h;  // (see above: not the skin of this K)
     if (K > 1 && (int)std::floor(prm->DL / (2.0 * prm->h + skin)) < 3) { K = 1; skin = 0.0; }
     c->rebuild_every = K;
     c->skin = skin;
     // Dynamic re-binning pays where a handful of empty launches per step is noise next to the passes (measured: the
     // host-driven forced rebuilds + cool-downs cost 10-25 % of the sustained rate from 0.5 M particles up).
     // dynamic_rebin: 0 = by size, 1 = on, 2 = off.
-    c->dyn = skin > 0.0 && (prm->dynamic_rebin == 1 || (prm->dynamic_rebin == 0 && nf >= 1000000));
+    c->dyn = skin > 0.0 && dyn_wanted;
 
     // grid: exact periodic tiling in x (cells >= 2h + skin), rows of 2h + skin in y over fluid + wall extent
     double y_min, y_max;
@@ -1800,9 +1817,13 @@ void slab_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, c
     // Re-binning interval of the slab: 1 = every step (the protocol of sphx_slab_compute / _finish, a caller-driven
     // transport); K > 1 (0 = auto: 5) = every K-th step with a cell skin, frozen layouts and fixed exchange lists in between
     // (the native loops sphx_slab_run / sphx_slab_group_run only).
-    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : 5;
+    // (round 4: a slab decides on the device like a dynamic context -- the skin of K = 5, scheduled re-binnings every 24th step,
+    //  see ctx_setup)
+    const bool auto_policy = prm->rebuild_every <= 0 && prm->skin_h <= 0.0;
+    int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : 24;
     const double d_step = 0.035 * prm->h;
     double skin = K > 1 ? (prm->skin_h > 0.0 ? prm->skin_h * prm->h : 2.0 * std::max((K - 1) * d_step, 0.1 * prm->h)) : 0.0;
+    if (auto_policy) skin = 0.28 * prm->h;
     c->rebuild_every = K;
     c->skin = skin;
     c->dyn = K > 1;  // the device decides when to re-bin (from all-reduced maxima), the layout is rebuilt in place

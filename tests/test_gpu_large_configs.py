@@ -4,11 +4,11 @@ particle (4 / 2 / 2) with the large-channel kernels (entries ahead, fluid / wall
 workgroups), the grid-stride re-binning kernels, size_t index products and, from 10^6 fluid particles, the
 device-decided ("dynamic") re-binning with its in-place reorder (k_copyback).
 
-Every case runs past the first scheduled re-binning (K = 8 at C3, 5 at C4 / C5), so the list rebuilt from the
-re-binned layout is compared as well.  All nine step outputs, the dt sequence (through t), max|v|, the pair
+Every case runs past the first scheduled re-binning (K = 8 at C3, 10 at C4, 24 from 10^6 particles -- round 4: the interval no
+longer sets the skin), so the list rebuilt from the re-binned layout is compared as well.  All nine step outputs, the dt sequence (through t), max|v|, the pair
 count of the rebuilt neighbour structure and the wall shear are compared particle by particle at the same
-tolerance as the small cases (rtol 1e-9 after <= 10 steps; reference loop: SPH_Poiseuille.m:250-292,
-neighbor.c:312-392, physics.c:857-957).  The oracle is serial C: ~2 us per particle-step (C5: ~70 s).
+tolerance as the small cases (rtol 1e-9 after <= 25 steps; reference loop: SPH_Poiseuille.m:250-292,
+neighbor.c:312-392, physics.c:857-957).  The oracle is serial C: ~1 us per particle-step (C5: ~140 s).
 """
 import numpy as np
 import pytest
@@ -27,11 +27,11 @@ CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False, fuse_e
          # workgroups, i.e. at C4 too (round 3)
          ("M194k", 0.01, 18.0, 10, dict(lpp=4, dynamic=False, big_scan=True, fuse_ea=True)),
          ("M259k", 0.01, 24.0, 10, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True)),
-         ("C4", 0.005, 12.0, 6, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True, forms=dict(tiles_abe=False, coded_lists=False))),
+         ("C4", 0.005, 12.0, 11, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True, forms=dict(tiles_abe=False, coded_lists=False))),
          # from 10^6 particles every pass stages an LDS tile and the lists name tile slots (slot-coded, round 3): the smallest
          # such channel and the largest configuration
-         ("M1250k", 0.004, 20.0, 6, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True))),
-         ("C5", 0.002, 24.0, 6, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True)))]
+         ("M1250k", 0.004, 20.0, 25, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True))),
+         ("C5", 0.002, 24.0, 25, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True)))]
 
 
 def _compare(name, prm, parts, n_steps, capi, oracle, expect, **ctx_kw):
@@ -81,7 +81,7 @@ def test_c4_dynamic_rebinning_matches_oracle(cfgmod, geom, capi, oracle):
     """0.5 M particles with the device-decided re-binning forced on and a skin small enough that the drift bound
     (not the schedule) triggers re-binnings inside the window: k_bin + the multi-block scan + k_copyback."""
     prm, parts = make_case(cfgmod, geom, dp=0.005, DL=12.0, jitter=0.2, seed=5, developed=True)
-    pol = _compare("C4dyn", prm, parts, 6, capi, oracle, dict(lpp=2, big_scan=True), dynamic_rebin=1, skin_h=0.05)
+    pol = _compare("C4dyn", prm, parts, 6, capi, oracle, dict(lpp=2, big_scan=True), dynamic_rebin=1, rebuild_every=5, skin_h=0.05)
     assert pol["forced_rebuilds"] >= 1, pol  # re-binnings triggered by the drift bound
 
 

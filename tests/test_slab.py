@@ -83,17 +83,19 @@ def test_slab_hip_two_ranks_half_million_particles():
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,dp,DL,steps,kw", [
     (2, 0.05, 3.0, 7, dict(rebuild_every=1)),                # re-binning every step: the protocol of compute / finish
-    (2, 0.05, 3.0, 23, dict()),                              # default: every 5th step, frozen layouts in between
-    (2, 0.05, 3.0, 23, dict(calls=[5, 5, 1, 9, 3])),         # ... in five calls, two of them ending on a re-binning step
+    (2, 0.05, 3.0, 27, dict()),                              # default: every 24th step or when the drift bound says so, frozen layouts in between
+    (2, 0.05, 3.0, 49, dict(calls=[5, 18, 1, 1, 23, 1])),    # ... in six calls, some of them ending on a scheduled re-binning step
+    (2, 0.05, 3.0, 23, dict(calls=[5, 5, 1, 9, 3], rebuild_every=5)),
     (3, 0.05, 4.5, 23, dict(rebuild_every=4)),
     (2, 0.04, 3.0, 17, dict(rebuild_every=8, skin_h=0.05)),  # skin far too thin: the drift bound triggers the re-binnings
-    (4, 0.01, 6.0, 12, dict()),
+    (4, 0.01, 6.0, 26, dict()),
     (2, 0.005, 12.0, 7, dict()),                             # 0.25 M particles per slab: multi-block scan, 2 lanes per particle
     (2, 0.004, 40.0, 7, dict()),                             # 1.25 M per slab: LDS tiles in every pass, slot-coded lists, stored tile layouts
     # four slabs of 0.25 M particles, each on a stream of its own and competing for the chip: k_slab_pack3's grid is many times
     # the workgroups a frozen step needs, so some are dispatched after the kernel's epilogue has advanced the clock -- they
-    # must still take the decision the others took (Clock::pos_q); 12 steps = two scheduled re-binnings and the steps before them
-    (4, 0.005, 24.0, 12, dict()),
+    # must still take the decision the others took (Clock::pos_q); 14 steps at K = 12: the scheduled re-binning, whatever
+    # the drift bound asks for on the way, and the steps before them
+    (4, 0.005, 24.0, 14, dict(rebuild_every=12, skin_h=0.28)),
     # the steps as ONE replayed hipGraph (sphx_slab_graph_prepare: ten steps per replay, kernels + copies + cross-stream
     # dependencies captured): prepared after the first call; 25 = two replays + five eager steps, and the last call finds
     # the other state parity -> eager again
