@@ -365,8 +365,17 @@ __global__ void k_prepare(Clock *clk, Phys ph, double t_target, long long max_st
 // ---------------------------------------------------------------------------------------------
 constexpr int kWallBit = 1 << 30;
 // nl_cnt[lane]: rows this lane owns (low half) and how many of them, the first ones, hold fluid neighbours (high half)
-__device__ __forceinline__ int list_rows(int packed) { return packed & 0xffff; }
+__device__ __forceinline__ int list_rows(int packed) { return packed & 0x3fff; }
 __device__ __forceinline__ int list_fluid_rows(int packed) { return packed >> 16; }
+// Bits 14 and 15 of a lane's packed counts (slot-coded lists only, see kSlotCodes): some fluid entry of the lane's column of the
+// SUPERSET list -- so of every list walked until the next re-binning -- names something beyond the first kForceSlots /
+// kSlotCodes slots of the workgroup's layout.  Set by the cell sweep, handed on by pass A's walk.  A wavefront none of whose
+// lanes has the bit reads its tile without looking at the entries (the `near` walks): the per-lane choice between the tile
+// and global memory is a pair of exec-mask regions around every fetch and, because both arms load into the same registers,
+// a wait for every outstanding global load -- the list words requested ahead -- in front of every LDS read.  Measured at 6 M
+// particles with a timing-only build whose fetches never look (profiles/r04_pretend_lds_only_fetch_*.txt): pass A's walk
+// 420 -> 369 us, KGC 252 -> 239, forces 522 -> 507, continuity 288 -> 275.
+constexpr int kFarForcesBit = 1 << 14, kFarTileBit = 1 << 15;
 
 // 16-bit entries of the large-channel lists (FluidTmp::nl_pk / sl_pk)
 constexpr int kDeltaMax = 32767;
@@ -400,6 +409,9 @@ __device__ __forceinline__ int encode_delta(int k, int i, int n, bool periodic, 
 // position in the workgroup's tile layout (tile_ranges at capacity kSlotCodes: own column, left, right -- a pass with a
 // smaller tile stages a prefix of the same layout); any other value is the index difference + kCodeBias (neighbours the
 // layout does not reach: a workgroup running across a column end, ranges longer than the layout).
+#ifndef SPHX_EXP_PRETEND_COMPLETE_TILE
+#define SPHX_EXP_PRETEND_COMPLETE_TILE 0  // measurement builds only (tools/probes/build_variant_lib.sh), see k_forces_w
+#endif
 constexpr int kSlotCodes = 480;
 constexpr int kForceSlots = 448;  // the force pass stages this many (88-byte records, four workgroups per CU)
 constexpr int kCodeBias = 33000;
@@ -1154,10 +1166,11 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     // ahead by whole words, the positions three rows (each requested into the register whose value has just been used -- a
     // rotating buffer would make every turn wait for the newest request); requests past the last row repeat it: no branch
     // around the loads, the values are not used.
-    auto fluid_rows = [&](auto fold) {
+    auto fluid_rows = [&](auto fold, auto near) {
         if (rows_fl <= 0) return;
         const int last = rows_fl - 1;
         constexpr bool kFold = decltype(fold)::value;
+        constexpr bool kNear = decltype(near)::value;  // every entry of the wavefront names a staged slot (kFarTileBit)
         auto word = [&](int p) { return t.sl_pk[(size_t)min(p, last >> 1) * t.nl_stride + tid]; };
         auto index = [&](int d) { return kFold ? wrap_index(i + d, n_now) : i + d; };
         auto row = [&](int d, const double2 &pj) {
@@ -1175,6 +1188,10 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
         if (TILE > 0) {  // positions from the tile (a few cycles away): only the entries run ahead
             auto fetch = [&](int e) -> double2 {  // (early return, not if/else: see k_kgc_w)
                 if (CODED) {
+#if SPHX_EXP_PRETEND_COMPLETE_TILE & 1
+                    return lds_double2(c_pos, min(e, kSlotCodes - 1));  // MEASUREMENT ONLY, see k_forces_w
+#endif
+                    if (kNear) return lds_double2(c_pos, e);
                     if (e < kSlotCodes) return lds_double2(c_pos, e);
                     return s.pos[wrap_index(i + e - kCodeBias, n_now)];
                 }
@@ -1215,8 +1232,10 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
             wa = wc; wb = wd; wc = we; wd = wf;
         }
     };
-    if (__any(active && near_seam(g, xi))) fluid_rows(std::true_type{});
-    else fluid_rows(std::false_type{});
+    const bool all_near = CODED && TILE > 0 && !__any(spacked & kFarTileBit);  // (see kFarTileBit)
+    if (__any(active && near_seam(g, xi))) fluid_rows(std::true_type{}, std::false_type{});
+    else if (CODED && all_near) fluid_rows(std::false_type{}, std::true_type{});
+    else fluid_rows(std::false_type{}, std::false_type{});
     int cnt_fl = cnt;
     for (int m = rows_fl; m < rows_all; ++m) {  // the mixed row and the wall rows
         bool acc = false, wall = false;
@@ -1246,7 +1265,8 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     if (active && cnt > t.nl_cap * LPP) { atomicOr(t.flags, 1); cnt = t.nl_cap * LPP; }
     cnt_fl = min(cnt_fl, cnt);
     if (tid < t.nl_stride)
-        t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
+        t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16) |
+                        (CODED ? spacked & (kFarForcesBit | kFarTileBit) : 0);
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {
@@ -1270,6 +1290,7 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
                                                      const FluidTmp &t, const Walls &w, int bid, int nblk, bool half)
 {
     static_assert(MODE == 0 || MODE == 1, "sweeping forms only");
+    __shared__ int far_parked[CODED ? kBlock : 1];
     SPHX_PASS_INDEX_AT(bid, nblk);
     if (beyond_population<LPP>(clk, t, blk)) return;
     const double2 pi = in_cap ? s.pos[i] : make_double2(0.0, 0.0);
@@ -1351,6 +1372,19 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
     // v -> particle index: two independent selects (a nested choice of three becomes branches, or a table in scratch memory)
     const int n01 = n0 + n1, off2 = lo[2] - n01, d12 = (lo[1] - n0) - off2, d01 = lo[0] - (lo[1] - n0);
     auto fluid_index = [&](int v) { return v + off2 + (v < n01 ? d12 : 0) + (v < n0 ? d01 : 0); };
+    // kFarTileBit / kFarForcesBit from the candidate ranges rather than from the entries handed out (a running maximum is one
+    // register more than this kernel has for six waves -- and so is this word, which waits in LDS until the counts are stored):
+    // each of the particle's three ranges must lie inside the layout's range of that column.  The lanes of a group agree; which of them stores an entry and which one walks it differ, but they sit in
+    // one wavefront, and wavefronts decide.
+    if (CODED) {
+        // (the particle's left / own / right range against the layout's second / first / third: a particle of the column the
+        //  layout was made for; any other one -- the tail of a workgroup that runs into the next column -- fails the test)
+        const bool miss = (n0 > 0 && (lo[0] < layout.lo1 || hi[0] > layout.lo1 + layout.len1)) ||
+                          (n1 > 0 && (lo[1] < layout.lo0 || hi[1] > layout.lo0 + layout.len0)) ||
+                          (n2 > 0 && (lo[2] < layout.lo2 || hi[2] > layout.lo2 + layout.len2));
+        const int top = n2 > 0 ? layout.len0 + layout.len1 + (hi[2] - layout.lo2) : (n0 > 0 ? layout.len0 + (hi[0] - layout.lo1) : hi[1] - layout.lo0);
+        far_parked[threadIdx.x] = miss ? (kFarForcesBit | kFarTileBit) : (top > kForceSlots ? kFarForcesBit : 0);
+    }
     // Two phases per chunk of 64 trips.  Only a third of the candidates of the 3 x 3 cells lie inside the (superset) radius,
     // and kernel value + packed list stores are four fifths of a trip's instructions: phase 1 only measures distances and
     // marks the trips inside the radius in a bit mask (positions requested three trips ahead, each into a register of its
@@ -1449,10 +1483,11 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
     cnt_fl = min(cnt_fl, cnt);
     if (record && active && scnt > t.sl_cap * LPP) { atomicOr(t.flags, 1); scnt = t.sl_cap * LPP; }
     scnt_fl = min(scnt_fl, scnt);
+    const int far_bits = CODED ? far_parked[threadIdx.x] : 0;
     if (tid < t.nl_stride)
-        t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16);
+        t.nl_cnt[tid] = (cnt > sub ? (cnt - sub + LPP - 1) / LPP : 0) | ((cnt_fl > sub ? (cnt_fl - sub + LPP - 1) / LPP : 0) << 16) | far_bits;
     if (record && tid < t.nl_stride)
-        t.sl_cnt[tid] = (scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0) | ((scnt_fl > sub ? (scnt_fl - sub + LPP - 1) / LPP : 0) << 16);
+        t.sl_cnt[tid] = (scnt > sub ? (scnt - sub + LPP - 1) / LPP : 0) | ((scnt_fl > sub ? (scnt_fl - sub + LPP - 1) / LPP : 0) << 16) | far_bits;
     s_in = group_sum<LPP>(s_in);
     s_ct = group_sum<LPP>(s_ct);
     if (active && sub == 0) {
@@ -1468,7 +1503,7 @@ __device__ __forceinline__ void density_sweep_body_w(const Clock *clk, int q, co
 // n_tiles: workgroup-sized tiles of the pass; the grid may be smaller (grid-stride over the tiles: the conditional launches
 // of a dynamic context, which are idle most of the time, see launch_physics)
 template <int LPP, int MODE, bool CODED = false>
-__global__ __launch_bounds__(kBlock) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CODED ? 6 : 5))) void k_density_sweep_w(const Clock *clk, int q, Grid g, Phys ph, FluidSet s,
                                                             FluidTmp t, Walls w, int cond_fresh, int n_tiles)
 {
     if (cond_fresh >= 0 && (clk->fresh != 0) != (cond_fresh != 0)) return;
@@ -1542,16 +1577,25 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     };
     auto fetch_code = [&](int e, double2 &pj, double &Volj) {  // (CODED; early return: see above)
         // (LDS-qualified reads: with plain ones the compiler folds both arms into FLAT loads through selected pointers)
+#if SPHX_EXP_PRETEND_COMPLETE_TILE & 2
+        e = min(e, kSlotCodes - 1);  // MEASUREMENT ONLY, see k_forces_w
+#endif
         if (e < kSlotCodes) { pj = lds_double2(c_pos, e); Volj = lds_double(c_vol, e); return; }
         const int k = wrap_index(i + e - kCodeBias, n_now);
         pj = s.pos[k]; Volj = t.vol[k];
     };
     const bool seam = __any(active && near_seam(g, xi));
+    const bool all_near = CODED && !__any(packed & kFarTileBit);  // (see kFarTileBit)
     if (CODED && seam)
         walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
             double2 pj; double Volj;
             fetch_code(e, pj, Volj);
             term(min_image(g, xi - pj.x), yi - pj.y, Volj);
+        });
+    else if (CODED && all_near)
+        walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
+            const double2 pj = lds_double2(c_pos, e);
+            term(xi - pj.x, yi - pj.y, lds_double(c_vol, e));
         });
     else if (CODED)
         walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
@@ -1651,6 +1695,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     const int n_staged = tm.total();
     auto fetch_code = [&](int e) {  // (CODED)
         FluidNb n;
+#if SPHX_EXP_PRETEND_COMPLETE_TILE & 4
+        // MEASUREMENT ONLY (tools/probes/build_variant_lib.sh -DSPHX_EXP_PRETEND_COMPLETE_TILE=<1 pass A | 2 B | 4 CD | 8 E>, never
+        // in libsphx.so): what would a particle order buy whose
+        // neighbourhoods fit TILE slots?  Entries the tile does not hold read some staged slot instead of global memory: the
+        // results are wrong, the instruction and memory streams are those of a complete tile (timed with sphx_ctx_time_kernel,
+        // which does not feed the outputs back into the state).
+        e = e < n_staged ? e : (e & 255);
+#endif
         if (e < n_staged) {  // (LDS-qualified reads: see k_kgc_w)
             const double2 vp = lds_double2(c_vp, e);
             n.p = lds_double2(c_pos, e); n.v = lds_double2(c_vel, e); n.a = make_double4(vp.x, vp.y, lds_double(c_rh, e), 0.0); n.B = lds_double4(c_B, e);
@@ -1706,10 +1758,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
         py -= pw * ty;
     };
     const bool seam = __any(active && near_seam(g, xi));
+    const bool all_near = CODED && TILE == kForceSlots && !__any(packed & kFarForcesBit);  // (see kFarTileBit)
     if (CODED && seam)
         walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
             const FluidNb n = fetch_code(e);
             fluid_pair(n, min_image(g, xi - n.p.x));
+        });
+    else if (CODED && all_near)
+        walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
+            FluidNb n;
+            const double2 vp = lds_double2(c_vp, e);
+            n.p = lds_double2(c_pos, e); n.v = lds_double2(c_vel, e); n.a = make_double4(vp.x, vp.y, lds_double(c_rh, e), 0.0); n.B = lds_double4(c_B, e);
+            fluid_pair(n, xi - n.p.x);
         });
     else if (CODED)
         walk_fluid_rows<true>(t, tid, i, rows_fl, w0, w1, [&](int e) {
@@ -2081,16 +2141,25 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
             rate += ((vxi - ujx) * ex + (vyi - ujy) * ey) * spline_dW_sel(ph.kc, r) * Volj;
         };
         auto fetch_code = [&](int e, double2 &pj, double2 &vj, double &Volj) {  // (CODED)
+#if SPHX_EXP_PRETEND_COMPLETE_TILE & 8
+            e = min(e, kSlotCodes - 1);  // MEASUREMENT ONLY, see k_forces_w
+#endif
             if (e < kSlotCodes) { pj = lds_double2(c_pos, e); vj = lds_double2(c_vel, e); Volj = lds_double(c_vol, e); return; }
             const int k = wrap_index(i + e - kCodeBias, n_now);
             pj = s.pos[k]; vj = t.veln[k]; Volj = t.vol[k];
         };
         const bool seam = __any(active && near_seam(g, xi));
+        const bool all_near = CODED && !__any(packed & kFarTileBit);  // (see kFarTileBit)
         if (CODED && seam)
             walk_fluid_rows<true>(t, tid, i, rows_fl, e_row0, e_row1, [&](int e) {
                 double2 pj, vj; double Volj;
                 fetch_code(e, pj, vj, Volj);
                 term(min_image(g, xi - pj.x), yi - pj.y, vj.x, vj.y, Volj);
+            });
+        else if (CODED && all_near)
+            walk_fluid_rows<true>(t, tid, i, rows_fl, e_row0, e_row1, [&](int e) {
+                const double2 pj = lds_double2(c_pos, e), vj = lds_double2(c_vel, e);
+                term(xi - pj.x, yi - pj.y, vj.x, vj.y, lds_double(c_vol, e));
             });
         else if (CODED)
             walk_fluid_rows<true>(t, tid, i, rows_fl, e_row0, e_row1, [&](int e) {

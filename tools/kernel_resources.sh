@@ -1,9 +1,9 @@
 #!/bin/bash
 # Registers, LDS and occupancy of every kernel of sphx_resident.hip as compiled for gfx950 (no GPU needed):
-#   tools/kernel_resources.sh [filter-regex] > table
+#   [SPHX_EXTRA_FLAGS=-D...] tools/kernel_resources.sh [filter-regex] > table
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 S=/tmp/sphx_resident_$$.s
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -o $S "$ROOT/sph-poiseuille-flow_amd/csrc/sphx_resident.hip" || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only $SPHX_EXTRA_FLAGS -S -o $S "$ROOT/sph-poiseuille-flow_amd/csrc/sphx_resident.hip" || exit 1
 python3 - "$S" "${1:-.}" <<'PY'
 import re, subprocess, sys
 txt = open(sys.argv[1]).read()
