@@ -1171,6 +1171,9 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
         const int last = rows_fl - 1;
         constexpr bool kFold = decltype(fold)::value;
         constexpr bool kNear = decltype(near)::value;  // every entry of the wavefront names a staged slot (kFarTileBit)
+        // (clamped by this lane's last word.  Clamping by the array instead makes the word's row x stride scalar arithmetic -- four
+        //  64-bit multiply-adds less per turn -- and was measured slower, 378 -> 387 us at 6 M particles: the words behind a
+        //  lane's last one are then real loads of lines nobody needs; profiles/r04_scalar_words_walk_c5.txt)
         auto word = [&](int p) { return t.sl_pk[(size_t)min(p, last >> 1) * t.nl_stride + tid]; };
         auto index = [&](int d) { return kFold ? wrap_index(i + d, n_now) : i + d; };
         auto row = [&](int d, const double2 &pj) {
@@ -1199,6 +1202,9 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
                 if (slot >= 0) return lds_double2(c_pos, slot);
                 return s.pos[k];
             };
+            // (measured on the near walk at 6 M particles and not kept, 375-383 us either way: the turn's words through a walking
+            //  pointer instead of word()'s two 64-bit multiply-adds; a turn's four tile reads requested together instead of one
+            //  LDS round trip at the head of every row -- profiles/r04_walking_pointer_walk_c5.txt, r04_batched_lds_walk_c5.txt)
             for (int m = 0; m < rows_fl; m += 4) {
                 const int we = word((m >> 1) + 4), wf = word((m >> 1) + 5);
                 const int d0 = CODED ? code_lo(wa) : delta_lo(wa), d1 = CODED ? code_hi(wa) : delta_hi(wa);
