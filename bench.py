@@ -96,12 +96,13 @@ def cpu_baseline(cfg, geo, prm, parts, budget_s=20.0):
                        f"{st['stats']['seconds_physics']:.1f}s OpenMP pair loops, {threads} threads)")
 
 
-def pmc_traffic(name, kernel):
+def pmc_traffic(name, kernel, key="traffic_bytes"):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
-    2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of MI355X_MICROARCH.md applied); None if not profiled."""
+    2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of MI355X_MICROARCH.md applied); None if not profiled.
+    key="valu_active_frac": the share of the launch's cycles in which its SIMDs issued vector-ALU instructions."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[name][{"k_continuity_clock": "k_continuity"}.get(kernel, kernel)]["traffic_bytes"]
+            return json.load(f)[name][{"k_continuity_clock": "k_continuity"}.get(kernel, kernel)][key]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -163,6 +164,9 @@ def run_case(capi, cfg, geo, name, kw, steps, warmup, profile_steps, lpp=0, spg=
                         # what the launch really moved through HBM, as a fraction of the peak (None without a PMC record)
                         hbm_frac=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                         traffic_over_algorithmic=(traffic / alg) if traffic and alg else None,
+                        # context for a low HBM fraction: the same committed passes' vector-ALU utilisation (the pair
+                        # arithmetic is FP64 on the vector ALU; the large-channel passes are bound there)
+                        valu_busy_pmc=pmc_traffic(name, dom, "valu_active_frac"),
                         traffic_source="profiles/pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE per launch from separate "
                                        "rocprofv3 --pmc passes of this kernel on this workload, committed -- not "
                                        "collected in this run (counters need the profiler)",
