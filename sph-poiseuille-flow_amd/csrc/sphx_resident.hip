@@ -2159,7 +2159,16 @@ void slab_native_buffers(sphx_ctx *c)
     c->msg_sl.alloc(n); c->msg_sr.alloc(n); c->msg_rl.alloc(n); c->msg_rr.alloc(n);
     c->vmax_l.alloc(2); c->vmax_g.alloc(2);
     for (DevBuf<double> *b : {&c->msg_sl, &c->msg_sr, &c->msg_rl, &c->msg_rr, &c->vmax_l, &c->vmax_g}) b->zero(c->stream);
-    if (c->rebuild_every > 1 && !debug_switches().no_slab_overlap) {  // the second stream of a skinned slab (k_slab_maxima)
+    // The second stream of a skinned slab (k_slab_maxima beside pass E, the exchange beside the interior of pass A) -- where there
+    // is something to hide the latencies behind: the two-stream step has five event hand-overs, one reduction kernel and one
+    // launch of pass A more than the chain, ~15 us on the critical path of a slab whose passes take 5 us each (ring of two C2
+    // slabs on one device 125 against 200-230 us/step), against an all-reduce and an exchange of 20-30 us each that pass E
+    // (>= 20 us) and the interior of pass A (>= 25 us) cover from ~150 k particles per slab.  Ranks may decide differently
+    // (unequal column counts): both forms issue the same sequence of RCCL calls.
+    // SPHX_SLAB_OVERLAP=always|never (read when a slab's buffers are made, not once per process: the tests run both forms).
+    const char *ov = std::getenv("SPHX_SLAB_OVERLAP");
+    const bool ov_always = ov && std::strcmp(ov, "always") == 0, ov_never = ov && std::strcmp(ov, "never") == 0;
+    if (c->rebuild_every > 1 && !debug_switches().no_slab_overlap && !ov_never && (c->cap >= 150000 || ov_always)) {
         SPHX_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         SPHX_HIP(hipEventCreateWithFlags(&c->ev_cd, hipEventDisableTiming));
         SPHX_HIP(hipEventCreateWithFlags(&c->ev_ar, hipEventDisableTiming));

@@ -87,6 +87,13 @@ def test_slab_hip_two_ranks_half_million_particles():
     (2, 0.05, 3.0, 49, dict(calls=[5, 18, 1, 1, 23, 1])),    # ... in six calls, some of them ending on a scheduled re-binning step
     (2, 0.05, 3.0, 23, dict(calls=[5, 5, 1, 9, 3], rebuild_every=5)),
     (3, 0.05, 4.5, 23, dict(rebuild_every=4)),
+    # the two-stream step (maxima + all-reduce beside pass E, the exchange beside the interior of pass A) is the default from
+    # 150 k particles per slab only: here it is asked for on small rings (SPHX_SLAB_OVERLAP), and refused on a large one below
+    (2, 0.05, 3.0, 49, dict(calls=[5, 18, 1, 1, 23, 1], overlap="always")),
+    (3, 0.05, 4.5, 23, dict(rebuild_every=4, overlap="always")),
+    (2, 0.04, 3.0, 17, dict(rebuild_every=8, skin_h=0.05, overlap="always")),
+    (4, 0.01, 6.0, 26, dict(overlap="always")),
+    (2, 0.005, 12.0, 7, dict(overlap="never")),
     (2, 0.04, 3.0, 17, dict(rebuild_every=8, skin_h=0.05)),  # skin far too thin: the drift bound triggers the re-binnings
     (4, 0.01, 6.0, 26, dict()),
     (2, 0.005, 12.0, 7, dict()),                             # 0.25 M particles per slab: multi-block scan, 2 lanes per particle
@@ -119,9 +126,14 @@ def test_slab_native_ring_in_one_process(world, dp, DL, steps, kw):
     kw = dict(kw)
     calls = kw.pop("calls", [steps])  # the run in several calls: the ids of a re-binning in a call's last step travel with the next call
     graph_after = kw.pop("graph_after", None)
+    overlap = kw.pop("overlap", None)  # which form of the skinned step (read by the library when a slab's buffers are made)
     assert sum(calls) == steps
-    engines = [slab.HipSlabEngine(prm, parts, r, world, 0, t_end=1e9, native=True, **kw) for r in range(world)]
+    env_before = os.environ.pop("SPHX_SLAB_OVERLAP", None)
+    if overlap:
+        os.environ["SPHX_SLAB_OVERLAP"] = overlap
+    engines = []
     try:
+        engines = [slab.HipSlabEngine(prm, parts, r, world, 0, t_end=1e9, native=True, **kw) for r in range(world)]
         for k_call, n_call in enumerate(calls):
             slab.HipSlabEngine.group_run(engines, n_call)
             if graph_after == k_call:
@@ -131,6 +143,9 @@ def test_slab_native_ring_in_one_process(world, dp, DL, steps, kw):
     finally:
         for e in engines:
             e.close()
+        os.environ.pop("SPHX_SLAB_OVERLAP", None)
+        if env_before is not None:
+            os.environ["SPHX_SLAB_OVERLAP"] = env_before
     pos, vel, drho = np.full((nf, 2), np.nan), np.full((nf, 2), np.nan), np.full(nf, np.nan)
     seen = np.zeros(nf, dtype=int)
     for sn in snaps:
