@@ -413,7 +413,7 @@ __device__ __forceinline__ int encode_delta(int k, int i, int n, bool periodic, 
 #define SPHX_EXP_PRETEND_COMPLETE_TILE 0  // measurement builds only (tools/probes/build_variant_lib.sh), see k_forces_w
 #endif
 constexpr int kSlotCodes = 480;
-constexpr int kForceSlots = 448;  // the force pass stages this many (88-byte records, four workgroups per CU)
+constexpr int kForceSlots = 464;  // the force pass stages this many (88-byte records: four workgroups of 40 864 B are the 160 KB of a CU)
 constexpr int kCodeBias = 33000;
 constexpr int kCodedDeltaMax = 32500;  // kSlotCodes <= kCodeBias - kCodedDeltaMax,  kCodeBias + kCodedDeltaMax <= 65535
 __device__ __forceinline__ int code_lo(int word) { return word & 0xffff; }
