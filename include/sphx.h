@@ -157,11 +157,11 @@ typedef struct sphx_params {
                                    between, sweeps are centred on the cell a particle was binned into and
                                    the cells carry a skin (results do not depend on K beyond summation
                                    order: the device stops and re-bins before any neighbour can be missed) */
-    int32_t dynamic_rebin;      /* device-decided re-binning (no host round trips): 0 = by size (on from 10^6 fluid
+    int32_t dynamic_rebin;      /* device-decided re-binning (no host round trips): 0 = by size (on from 2 x 10^6 fluid
                                    particles), 1 = on, 2 = off                                              */
     double skin_h;              /* cell skin in units of h for K > 1; <= 0 = sized from K.  Both left at 0: the
                                    measured pair for the size class (K = 16 up to 20 k fluid particles, 8 up to 300 k,
-                                   10 with 0.42 h up to 10^6, 24 with 0.28 h where the device re-bins by itself)  */
+                                   10 with 0.42 h up to 2 x 10^6, 24 with 0.28 h where the device re-bins by itself)  */
 } sphx_params;
 
 typedef struct sphx_status {

@@ -1220,14 +1220,19 @@ void ctx_setup(sphx_ctx *c, const sphx_params *prm, int n_fluid, int n_total, co
     // of K = 5 and K goes up: C5 1 632 -> 1 507 us/step in bench.py's window at K = 12, 1 723 -> 1 598 sustained (K = 12 with
     // 0.31 h: 1 514 / 1 603); on another box K = 12 / 16 / 24 / 64: 1 550 / 1 523 / 1 503 / 1 493 in the window, 1 645 sustained for
     // all four (the drift bound decides there) -> 24.  1.25 M particles 384 -> 354 / 413 -> 401.  On the host-driven schedule a
-    // drift stop is a round trip and a cool-down, so the skin has to grow with K: 0.3-1 M particles K = 10 with 0.42 h (C4 160 ->
+    // drift stop is a round trip and a cool-down, so the skin has to grow with K: 0.3-2 M particles K = 10 with 0.42 h (C4 160 ->
     // 157 in the window, 170 -> 164 sustained, one forced re-binning in 3 000 steps; K = 8 with 0.28 h: 17 of them, 263 us/step).
     // Up to 20 k particles K = 16 stays: K = 24 on the same skin (1.05 h) is 3 % faster on the bench's flow (C2 17.4 -> 16.8
     // us/step, C1 14.2 -> 13.7, no forced re-binning in 12 000 developed steps) but a flow AT the reference's U_max drifts
     // 0.023 h a step -- 23 steps of that are the whole half-skin, and tests/test_gpu_headline_parity.py's state forced 16
     // re-binnings in 50 steps with it (K = 32: 86 in the bench's own flow, 50 us/step); 20 k - 300 k stays at 8 (every other
     // pair measured slower there: profiles/r04_k_skin_c3.txt, _194k.txt).
-    const bool dyn_wanted = prm->dynamic_rebin == 1 || (prm->dynamic_rebin == 0 && nf >= 1000000);
+    // Who re-bins: the device by itself from 2 x 10^6 particles (round 4; 10^6 before the wider skins).  Measured with K = 10 /
+    // 0.42 h on the host's schedule against K = 24 / 0.28 h on the device's (window / sustained us/step, profiles/
+    // r04_static_vs_dyn_*.txt): 1.25 M particles 338 / 353 against 337-340 / 381-384, 2.5 M 664 / 685 against 636 / 705,
+    // 6 M 1 526 / 1 564 against 1 407 / 1 542 -- the self-skipping launches of a device-decided step are 7 % of a step at
+    // 1.25 M and 1.7 % at 6 M, the thin skin's shorter lists are worth more the longer the passes.
+    const bool dyn_wanted = prm->dynamic_rebin == 1 || (prm->dynamic_rebin == 0 && nf >= 2000000);
     const bool auto_policy = prm->rebuild_every <= 0 && prm->skin_h <= 0.0;
     int K = prm->rebuild_every > 0 ? std::min(prm->rebuild_every, 64) : (nf <= 20000 ? 16 : (nf <= 300000 ? 8 : (dyn_wanted ? 24 : 10)));
     // dual-rate loop: a slot moves particles n_sub times as far.  Same eligibility as ctx_alloc's n_in (the fused E|A launch

@@ -291,7 +291,7 @@ def test_narrow_domain_falls_back_to_every_step(cfgmod, geom, capi):
         assert ctx.advance(1e9, max_steps=3)["step"] == 3
 
 
-# ---- dynamic re-binning (the device decides when to re-bin; default from 10^6 particles, forced on here) -------------
+# ---- dynamic re-binning (the device decides when to re-bin; default from 2 x 10^6 particles, forced on here) -------------
 
 @pytest.mark.parametrize("kw", [dict(rebuild_every=5), dict(rebuild_every=8, skin_h=0.03), dict(rebuild_every=3)])
 @pytest.mark.parametrize("n_steps", [1, 4, 9, 17])

@@ -4,7 +4,7 @@ particle (4 / 2 / 2) with the large-channel kernels (entries ahead, fluid / wall
 workgroups), the grid-stride re-binning kernels, size_t index products and, from 10^6 fluid particles, the
 device-decided ("dynamic") re-binning with its in-place reorder (k_copyback).
 
-Every case runs past the first scheduled re-binning (K = 8 at C3, 10 at C4, 24 from 10^6 particles -- round 4: the interval no
+Every case runs past the first scheduled re-binning (K = 8 at C3, 10 at C4 and at 1.25 M, 24 where the device re-bins by itself (from 2 x 10^6 particles) -- round 4: the interval no
 longer sets the skin), so the list rebuilt from the re-binned layout is compared as well.  All nine step outputs, the dt sequence (through t), max|v|, the pair
 count of the rebuilt neighbour structure and the wall shear are compared particle by particle at the same
 tolerance as the small cases (rtol 1e-9 after <= 25 steps; reference loop: SPH_Poiseuille.m:250-292,
@@ -30,7 +30,8 @@ CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False, fuse_e
          ("C4", 0.005, 12.0, 11, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True, forms=dict(tiles_abe=False, coded_lists=False))),
          # from 10^6 particles every pass stages an LDS tile and the lists name tile slots (slot-coded, round 3): the smallest
          # such channel and the largest configuration
-         ("M1250k", 0.004, 20.0, 25, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True))),
+         # (host-scheduled up to 2 x 10^6 particles since round 4: K = 10 on the wider skin)
+         ("M1250k", 0.004, 20.0, 13, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True))),
          ("C5", 0.002, 24.0, 25, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True)))]
 
 
@@ -83,6 +84,15 @@ def test_c4_dynamic_rebinning_matches_oracle(cfgmod, geom, capi, oracle):
     prm, parts = make_case(cfgmod, geom, dp=0.005, DL=12.0, jitter=0.2, seed=5, developed=True)
     pol = _compare("C4dyn", prm, parts, 6, capi, oracle, dict(lpp=2, big_scan=True), dynamic_rebin=1, rebuild_every=5, skin_h=0.05)
     assert pol["forced_rebuilds"] >= 1, pol  # re-binnings triggered by the drift bound
+
+
+def test_device_decided_rebinning_at_1p25m_matches_oracle(cfgmod, geom, capi, oracle):
+    """The smallest slot-coded channel with the device-decided re-binning asked for (the default from 2 x 10^6 particles):
+    K = 24 on the thin skin, in-place reorder, far bits of the re-binned lists."""
+    prm, parts = make_case(cfgmod, geom, dp=0.004, DL=20.0, jitter=0.2, seed=11, developed=True)
+    _compare("M1250k-dyn", prm, parts, 25, capi, oracle,
+             dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True)),
+             dynamic_rebin=1)
 
 
 def test_c3_lattice_start_matches_oracle(cfgmod, geom, capi, oracle):
