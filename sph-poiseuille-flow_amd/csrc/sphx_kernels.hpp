@@ -997,6 +997,23 @@ struct TileMap {
         return m;
     }
 };
+#ifndef SPHX_EXP_N2_PROLOGUE
+#define SPHX_EXP_N2_PROLOGUE 0  // measurement builds only (tools/probes/build_variant_lib.sh)
+#endif
+// MEASUREMENT ONLY: what decoding a layout of 3 + 14 ranges would add to every staged slot (a blocked particle order's tile
+// neighbourhood: the strip's own run plus one cell above and below per column).  Fourteen compare / select /
+// add steps on values the compiler cannot fold; the result is 0, so the staged data -- and every result -- stay what they are.
+__device__ __forceinline__ int n2_prologue_cost(int sl, const TileMap &m)
+{
+#if SPHX_EXP_N2_PROLOGUE
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) acc = sl >= m.len0 + m.len1 + m.len2 + 1000 + 37 * j ? acc + m.lo0 + j : acc;
+    return acc;
+#else
+    return 0;
+#endif
+}
 // The layout (tile_ranges at capacity kSlotCodes) of every workgroup is worked out ONCE per re-binning, by the cell sweep, and
 // kept in FluidTmp::tmap.  Working it out in every pass put two dependent memory round trips (first / last cell of the
 // workgroup -> six cell starts) in front of the staging loads, in a prologue that already waits for the clock: the workgroups
@@ -1116,7 +1133,7 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     TileMap tm{0, 0, 0, 0, 0, 0};
     if (TILE > 0) {  // candidate positions of the workgroup's three-column neighbourhood staged in LDS (see tile_ranges)
         tm = staged_map<LPP>(layout, blk, n_now, TILE);
-        for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) c_pos[sl] = s.pos[tm.index(sl)];
+        for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) c_pos[sl] = s.pos[tm.index(sl) + n2_prologue_cost(sl, tm)];
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
@@ -1555,7 +1572,7 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     if (TILE > 0) {
         tm = staged_map<LPP>(layout, blk, n_now, TILE);
         for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
-            const int k = tm.index(sl);
+            const int k = tm.index(sl) + n2_prologue_cost(sl, tm);
             c_pos[sl] = s.pos[k];
             c_vol[sl] = t.vol[k];
         }
@@ -1688,7 +1705,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     if (TILE > 0) {
         tm = staged_map<LPP>(layout, blk, n_now, TILE);
         for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
-            const int k = tm.index(sl);
+            const int k = tm.index(sl) + n2_prologue_cost(sl, tm);
             c_pos[sl] = s.pos[k];
             c_vel[sl] = s.vel[k];
             const double4 ak = t.a[k];
@@ -2127,7 +2144,7 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
         if (TILE > 0) {
             tm = staged_map<LPP>(layout, blk, n_now, TILE);
             for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
-                const int k = tm.index(sl);
+                const int k = tm.index(sl) + n2_prologue_cost(sl, tm);
                 c_pos[sl] = s.pos[k];
                 c_vel[sl] = t.veln[k];
                 c_vol[sl] = t.vol[k];
