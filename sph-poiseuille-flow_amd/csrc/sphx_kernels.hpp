@@ -1133,7 +1133,17 @@ __device__ __forceinline__ void density_walk_body(const Clock *clk, int q, const
     TileMap tm{0, 0, 0, 0, 0, 0};
     if (TILE > 0) {  // candidate positions of the workgroup's three-column neighbourhood staged in LDS (see tile_ranges)
         tm = staged_map<LPP>(layout, blk, n_now, TILE);
-        for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) c_pos[sl] = s.pos[tm.index(sl) + n2_prologue_cost(sl, tm)];
+        static_assert(TILE <= 2 * kBlock, "two slots per thread");
+        {  // (both of a thread's slots requested before either is waited for: see k_forces_w)
+            const int total = tm.total(), sl0 = threadIdx.x, sl1 = threadIdx.x + kBlock;
+            const bool h0 = sl0 < total, h1 = sl1 < total;
+            const int k0 = tm.index(h0 ? sl0 : 0) + n2_prologue_cost(sl0, tm), k1 = tm.index(h1 ? sl1 : 0) + n2_prologue_cost(sl1, tm);
+            double2 p0, p1;
+            if (h0) p0 = s.pos[k0];
+            if (h1) p1 = s.pos[k1];
+            if (h0) c_pos[sl0] = p0;
+            if (h1) c_pos[sl1] = p1;
+        }
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, gbase = lane & ~(LPP - 1);
@@ -1571,10 +1581,17 @@ __global__ __launch_bounds__(kBlock) void k_kgc_w(const Clock *clk, int q, Grid 
     TileMap tm{0, 0, 0, 0, 0, 0};
     if (TILE > 0) {
         tm = staged_map<LPP>(layout, blk, n_now, TILE);
-        for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
-            const int k = tm.index(sl) + n2_prologue_cost(sl, tm);
-            c_pos[sl] = s.pos[k];
-            c_vol[sl] = t.vol[k];
+        static_assert(TILE <= 2 * kBlock, "two slots per thread");
+        {  // (both of a thread's slots requested before either is waited for: see k_forces_w)
+            const int total = tm.total(), sl0 = threadIdx.x, sl1 = threadIdx.x + kBlock;
+            const bool h0 = sl0 < total, h1 = sl1 < total;
+            const int k0 = tm.index(h0 ? sl0 : 0) + n2_prologue_cost(sl0, tm), k1 = tm.index(h1 ? sl1 : 0) + n2_prologue_cost(sl1, tm);
+            double2 p0, p1;
+            double u0, u1;
+            if (h0) { p0 = s.pos[k0]; u0 = t.vol[k0]; }
+            if (h1) { p1 = s.pos[k1]; u1 = t.vol[k1]; }
+            if (h0) { c_pos[sl0] = p0; c_vol[sl0] = u0; }
+            if (h1) { c_pos[sl1] = p1; c_vol[sl1] = u1; }
         }
         __syncthreads();
     }
@@ -1704,14 +1721,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(TILE > 4
     TileMap tm{0, 0, 0, 0, 0, 0};
     if (TILE > 0) {
         tm = staged_map<LPP>(layout, blk, n_now, TILE);
-        for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
-            const int k = tm.index(sl) + n2_prologue_cost(sl, tm);
-            c_pos[sl] = s.pos[k];
-            c_vel[sl] = s.vel[k];
-            const double4 ak = t.a[k];
-            c_vp[sl] = make_double2(ak.x, ak.y);
-            c_rh[sl] = ak.z;
-            c_B[sl] = t.B[k];
+        // (a thread stages up to two slots: both requested before either is waited for -- as a loop, the second trip's
+        //  loads left only after the first trip's had come back and gone to LDS: a memory round trip more in the prologue
+        //  every workgroup of the CU waits through)
+        static_assert(TILE <= 2 * kBlock, "two slots per thread");
+        {
+            const int total = tm.total(), sl0 = threadIdx.x, sl1 = threadIdx.x + kBlock;
+            const bool h0 = sl0 < total, h1 = sl1 < total;
+            const int k0 = tm.index(h0 ? sl0 : 0) + n2_prologue_cost(sl0, tm), k1 = tm.index(h1 ? sl1 : 0) + n2_prologue_cost(sl1, tm);
+            double2 p0, v0, p1, v1;
+            double4 a0, B0, a1, B1;
+            if (h0) { p0 = s.pos[k0]; v0 = s.vel[k0]; a0 = t.a[k0]; B0 = t.B[k0]; }
+            if (h1) { p1 = s.pos[k1]; v1 = s.vel[k1]; a1 = t.a[k1]; B1 = t.B[k1]; }
+            if (h0) { c_pos[sl0] = p0; c_vel[sl0] = v0; c_vp[sl0] = make_double2(a0.x, a0.y); c_rh[sl0] = a0.z; c_B[sl0] = B0; }
+            if (h1) { c_pos[sl1] = p1; c_vel[sl1] = v1; c_vp[sl1] = make_double2(a1.x, a1.y); c_rh[sl1] = a1.z; c_B[sl1] = B1; }
         }
         __syncthreads();
     }
@@ -2143,11 +2166,17 @@ __device__ __forceinline__ void continuity_body(Clock *clk, int q, const Grid &g
         TileMap tm{0, 0, 0, 0, 0, 0};
         if (TILE > 0) {
             tm = staged_map<LPP>(layout, blk, n_now, TILE);
-            for (int sl = threadIdx.x; sl < tm.total(); sl += kBlock) {
-                const int k = tm.index(sl) + n2_prologue_cost(sl, tm);
-                c_pos[sl] = s.pos[k];
-                c_vel[sl] = t.veln[k];
-                c_vol[sl] = t.vol[k];
+            static_assert(TILE <= 2 * kBlock, "two slots per thread");
+            {  // (both of a thread's slots requested before either is waited for: see k_forces_w)
+                const int total = tm.total(), sl0 = threadIdx.x, sl1 = threadIdx.x + kBlock;
+                const bool h0 = sl0 < total, h1 = sl1 < total;
+                const int k0 = tm.index(h0 ? sl0 : 0) + n2_prologue_cost(sl0, tm), k1 = tm.index(h1 ? sl1 : 0) + n2_prologue_cost(sl1, tm);
+                double2 p0, p1, v0, v1;
+                double u0, u1;
+                if (h0) { p0 = s.pos[k0]; v0 = t.veln[k0]; u0 = t.vol[k0]; }
+                if (h1) { p1 = s.pos[k1]; v1 = t.veln[k1]; u1 = t.vol[k1]; }
+                if (h0) { c_pos[sl0] = p0; c_vel[sl0] = v0; c_vol[sl0] = u0; }
+                if (h1) { c_pos[sl1] = p1; c_vel[sl1] = v1; c_vol[sl1] = u1; }
             }
             __syncthreads();
         }
