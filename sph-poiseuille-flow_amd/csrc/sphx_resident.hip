@@ -1165,7 +1165,12 @@ void choose_kernel_forms(sphx_ctx *c, bool lpp_given, double column_load, int n_
     //  A slab has no fused launch to give up: in-process rings of 0.51 M / 0.76 M-particle slabs run 5 % / 9 % faster with the
     //  tiles (C5 as 12 / 8 slabs: 2 970 -> 2 821, 2 546 -> 2 323 us/step), 0.25 M-particle slabs do not (276 / 279); a single
     //  context of 0.76 M particles is a tie (239.5 / 239.8).
-    const int tiles_from = dbg.tiles_be_from > 0 ? dbg.tiles_be_from : (c->is_slab ? 500000 : 1000000);
+    //  Round 4 (walks that do not look at the entry, two-slot staging): a single context takes the tiles from where the fused
+    //  E|A launch ends (4096 workgroups per pass = 524 k particles at 2 lanes each) -- 0.59 M particles 189 / 198 -> 181 / 186
+    //  us/step (window / sustained), 0.79 M 242 / 257 -> 231 / 240; below, the fused launch is worth more: 0.52 M 165 / 172
+    //  fused against 170 / 176 with tiles (profiles/r04_tiles_from_*.txt).  It was 10^6 before.
+    const bool fits_fused = div_up((size_t)std::max(n_resident, 0) * (size_t)c->lpp, (size_t)kBlock) <= (size_t)tail_clock_limit();
+    const int tiles_from = dbg.tiles_be_from > 0 ? dbg.tiles_be_from : (c->is_slab ? 500000 : (fits_fused ? 1000000 : 0));
     c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= tiles_from;
     c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
     // every pass stages the same layout: the lists can name its slots (kSlotCodes) -- the index differences that remain need a
