@@ -1169,8 +1169,10 @@ void choose_kernel_forms(sphx_ctx *c, bool lpp_given, double column_load, int n_
     //  E|A launch ends (4096 workgroups per pass = 524 k particles at 2 lanes each) -- 0.59 M particles 189 / 198 -> 181 / 186
     //  us/step (window / sustained), 0.79 M 242 / 257 -> 231 / 240; below, the fused launch is worth more: 0.52 M 165 / 172
     //  fused against 170 / 176 with tiles (profiles/r04_tiles_from_*.txt).  It was 10^6 before.
+    //  Slabs: from 0.3 M particles held (0.5 M before): C5 as 16 slabs of 0.39 M 3 539 -> 3 221 us/step in an in-process ring,
+    //  slabs of 0.24 M 290 / 290 (profiles/r04_slab_tiles_from.txt).
     const bool fits_fused = div_up((size_t)std::max(n_resident, 0) * (size_t)c->lpp, (size_t)kBlock) <= (size_t)tail_clock_limit();
-    const int tiles_from = dbg.tiles_be_from > 0 ? dbg.tiles_be_from : (c->is_slab ? 500000 : (fits_fused ? 1000000 : 0));
+    const int tiles_from = dbg.tiles_be_from > 0 ? dbg.tiles_be_from : (c->is_slab ? 300000 : (fits_fused ? 1000000 : 0));
     c->lds_tiles_be = c->lds_tiles && c->lpp <= 2 && n_resident >= tiles_from;
     c->lds_tiles_a = c->lds_tiles_be;  // (6 M particles: 450 with, 478 us without; 0.5 M: 50.5 with, 42.3 without)
     // every pass stages the same layout: the lists can name its slots (kSlotCodes) -- the index differences that remain need a
