@@ -30,6 +30,9 @@ CASES = [("C3", 0.01, 6.0, 10, dict(lpp=4, dynamic=False, big_scan=False, fuse_e
          ("C4", 0.005, 12.0, 11, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=True, forms=dict(tiles_abe=False, coded_lists=False))),
          # from 10^6 particles every pass stages an LDS tile and the lists name tile slots (slot-coded, round 3): the smallest
          # such channel and the largest configuration
+         # the smallest channel past the fused E|A launch (4096 workgroups per pass = 524 k particles): tiles in every pass and
+         # slot-coded lists start here since round 4 (10^6 before), on the host's schedule
+         ("M590k", 0.0045, 12.0, 13, dict(lpp=2, dynamic=False, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True))),
          # (host-scheduled up to 2 x 10^6 particles since round 4: K = 10 on the wider skin)
          ("M1250k", 0.004, 20.0, 13, dict(lpp=2, dynamic=False, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True))),
          ("C5", 0.002, 24.0, 25, dict(lpp=2, dynamic=True, big_scan=True, fuse_ea=False, forms=dict(lds_tiles=True, tiles_abe=True, coded_lists=True)))]
